@@ -1,0 +1,215 @@
+/*
+ * slm_hip.h -- C ABI of libslm_hip.so: the MI355X (gfx950 / CDNA4) kernel library
+ * behind ScaleLLM's decode hot path.
+ *
+ * Drop-in boundary: every entry point below replaces one C++ kernel-level
+ * symbol of the reference (vectorch-ai/ScaleLLM, paths relative to the
+ * reference root).  The reference passes torch::Tensor; a thin libtorch shim
+ * (scalellm_amd/csrc/shim/) adapts tensor -> (pointer,
+ * strides, sizes) and calls these functions, so the reference src/layers tree compiles
+ * unchanged.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes only; no torch / C++ types;
+ *   - device pointers unless stated "host";
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); never
+ *     synchronises, never allocates, never reads device memory on the host --
+ *     therefore safe under hipGraph stream capture
+ *     (reference: src/engine/model_runner.cpp:141-178);
+ *   - returns 0 (SLM_OK) or a negative slm_status; never aborts;
+ *   - thread-safe per stream (one Worker thread per GPU in the reference:
+ *     src/engine/worker.cpp:202-213).
+ */
+#ifndef SLM_HIP_H_
+#define SLM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLM_API __attribute__((visibility("default")))
+
+typedef enum slm_status {
+  SLM_OK = 0,
+  SLM_ERR_INVALID_ARG = -1,   /* null pointer, bad size, non power-of-two block_size ... */
+  SLM_ERR_UNSUPPORTED = -2,   /* dtype / head_dim / bits / group not supported */
+  SLM_ERR_WORKSPACE = -3,     /* workspace missing or too small */
+  SLM_ERR_LAUNCH = -4,        /* hipLaunchKernel reported an error */
+  SLM_ERR_ALIGNMENT = -5      /* pointer or stride not 16-byte aligned */
+} slm_status;
+
+typedef enum slm_dtype {
+  SLM_F16 = 0,  /* IEEE half   (torch::kHalf)     */
+  SLM_BF16 = 1  /* bfloat16    (torch::kBFloat16) */
+} slm_dtype;
+
+SLM_API const char* slm_status_string(int status);
+SLM_API const char* slm_version(void);
+
+/* ========================================================================== */
+/* 1. Paged-KV varlen attention (prefill / chunked prefill / decode / verify) */
+/*    replaces  llm::paged_kv_varlen_mha                                      */
+/*              src/kernels/attention/attn_api.h:12-27 (impl attn_api.cpp:14) */
+/*    caller    ScaleAttnHandler::batch_decode                                */
+/*              src/layers/attention/scale_attn_handler.cpp:44-68             */
+/*    params    mirror MHAPagedKVParams, src/kernels/attention/mha_params.h   */
+/*              :11-117 (strides in ELEMENTS; last dim contiguous).           */
+/*    Block table = flattened first-slot ids + CSR offsets                    */
+/*    (src/engine/batch.cpp:206-209, src/models/parameters.h:50-55);          */
+/*    slot(kv_idx) = block_table[block_cu_lens[b] + (kv_idx >> log2(bs))]     */
+/*                   + (kv_idx & (bs-1))   (kernel/sm80_kernel_mha.cuh:146).  */
+/* ========================================================================== */
+typedef struct slm_attn_args {
+  void* out;                /* [n_tokens, n_heads, head_dim]                  */
+  const void* query;        /* [n_tokens, n_heads, head_dim]                  */
+  const void* key_cache;    /* [n_slots, n_kv_heads, head_dim]                */
+  const void* value_cache;  /* [n_slots, n_kv_heads, head_dim]                */
+  int64_t o_stride[2];      /* {token stride, head stride} in elements        */
+  int64_t q_stride[2];
+  int64_t k_stride[2];      /* {slot stride, head stride}                     */
+  int64_t v_stride[2];
+  const int32_t* q_cu_lens;      /* [batch+1]                                 */
+  const int32_t* kv_cu_lens;     /* [batch+1]                                 */
+  const int32_t* block_table;    /* [sum_b ceil(kv_len_b / block_size)]       */
+  const int32_t* block_cu_lens;  /* [batch+1]                                 */
+  const float* alibi_slopes;     /* [n_heads] or NULL                         */
+  int32_t dtype;            /* slm_dtype of out/query/caches                  */
+  int32_t batch_size;
+  int32_t n_tokens;         /* = query.size(0) = q_cu_lens[batch]             */
+  int32_t n_heads;
+  int32_t n_kv_heads;
+  int32_t head_dim;         /* multiple of 8, <= 256                          */
+  int32_t block_size;       /* power of two (mha_params.h:71-74)              */
+  int32_t max_q_len;        /* scheduling hint, as in the reference           */
+  int32_t max_kv_len;       /* scheduling hint (unused by the reference)      */
+  float sm_scale;
+  float logits_soft_cap;    /* 0 = off                                        */
+  int32_t sliding_window;   /* -1 = off                                       */
+  void* workspace;          /* split-KV scratch, may be NULL if bytes == 0    */
+  size_t workspace_bytes;
+  int32_t num_splits;       /* 0 = auto (heuristic); >0 forces the split count */
+  int32_t reserved;
+} slm_attn_args;
+
+/* Scratch needed for `a` (depends only on host-side sizes; AttentionHandler::
+ * get_estimate_workspace_size / set_workspace, src/layers/attention/handler.h
+ * :40-47 is the natural home).  Pass num_splits to query a forced split count.*/
+SLM_API size_t slm_paged_kv_varlen_mha_workspace_bytes(const slm_attn_args* a);
+/* Split count the heuristic would pick for `a` (host-side sizes only).        */
+SLM_API int32_t slm_paged_kv_varlen_mha_auto_splits(const slm_attn_args* a);
+SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream);
+
+/* ========================================================================== */
+/* 2. KV-cache append                                                         */
+/*    replaces  llm::kernel::set_kv_cache                                     */
+/*              src/kernels/kv_cache_kernels.h:6-11 (.cu:9-78)                */
+/*    caller    KVCache::set_kv_cache_cuda  src/memory/kv_cache.cpp:53-57     */
+/*    cache[slot_ids[t], h, d] = kv[t, h, d] for K and V (bit-exact copy).    */
+/* ========================================================================== */
+SLM_API int slm_set_kv_cache(const int32_t* slot_ids,  /* [n_tokens]           */
+                             const void* keys,         /* [n_tokens, n_kv_heads, head_dim] */
+                             const void* values,
+                             int64_t k_token_stride,   /* elements             */
+                             int64_t v_token_stride,
+                             void* key_cache,          /* [n_slots, n_kv_heads, head_dim] contiguous */
+                             void* value_cache,
+                             int64_t n_tokens, int32_t n_kv_heads, int32_t head_dim,
+                             int32_t dtype, void* stream);
+
+/* ========================================================================== */
+/* 3. int4 weight prepack (checkpoint format -> MFMA-native layout)           */
+/*    replaces  marlin::gptq_repack / marlin::awq_repack                      */
+/*              src/kernels/quantization/marlin.h:27-35                       */
+/*              (gptq_repack.cu:252, awq_repack.cu:191) and the host-side     */
+/*              scale / zero-point permutations of                            */
+/*              qlinear_awq_marlin_impl.cpp:34-125,                           */
+/*              qlinear_gptq_marlin_impl.cpp:41-71.                           */
+/*    Inputs are the stable on-disk formats:                                  */
+/*      GPTQ: qweight [K/8, N] int32 (nibble k%8 at bit 4*(k%8)),             */
+/*            qzeros  [G, N/8] int32 (plain order, zero = stored + 1),        */
+/*            scales  [G, N] T, optional g_idx [K] (act-order);               */
+/*      AWQ : qweight [K, N/8] int32, qzeros [G, N/8] int32, both with the    */
+/*            [0,2,4,6,1,3,5,7] nibble interleave, zero = stored;             */
+/*            scales  [G, N] T.                                               */
+/*    Output layout (owned by this library):                   */
+/*      wq  [N/32][K/64][64 lanes][4] uint32  -- lane l, word j holds the 8   */
+/*           nibbles n = 32*nt + (l&31), k = 64*kt + 16*j + 8*(l>>5) + p'     */
+/*           in a pair-interleaved nibble order (MFMA 32x32x16 B-fragment);   */
+/*      sz  [G][N] {scale, -zero*scale} as 2 x T  (fused scale/zero table);   */
+/*      perm[K] int32 (act-order only): row k' of wq = checkpoint row perm[k']*/
+/* ========================================================================== */
+typedef enum slm_w4_format { SLM_W4_GPTQ = 0, SLM_W4_AWQ = 1 } slm_w4_format;
+
+SLM_API size_t slm_w4_packed_weight_bytes(int64_t K, int64_t N);
+SLM_API size_t slm_w4_packed_sz_bytes(int64_t K, int64_t N, int64_t group_size);
+
+SLM_API int slm_w4_prepack(int32_t format,            /* slm_w4_format          */
+                           const int32_t* qweight, const int32_t* qzeros,
+                           const void* scales,        /* [G, N] T               */
+                           const int32_t* perm,       /* [K] sorted-row -> ckpt-row, or NULL */
+                           int64_t K, int64_t N, int64_t group_size, int32_t dtype,
+                           void* wq_out, void* sz_out, void* stream);
+
+/* ========================================================================== */
+/* 4. int4-weight x fp16/bf16-activation GEMM  C[M,N] = A[M,K] . dequant(W)   */
+/*    replaces  marlin::gptq_gemm  src/kernels/quantization/marlin.h:17-25    */
+/*              (gptq_gemm.cu:585-710) incl. permute_cols_kernel              */
+/*              (gptq_gemm.cu:69-118) for act-order.                          */
+/*    callers   {Column,Row}ParallelQLinear{AWQ,GPTQ}MarlinImpl::forward      */
+/*              qlinear_awq_marlin_impl.cpp:238,344;                          */
+/*              qlinear_gptq_marlin_impl.cpp:188,310.                         */
+/*    w = scale * (q - zero); fp32 accumulate; output rounded RN to T.        */
+/* ========================================================================== */
+typedef struct slm_w4_gemm_args {
+  const void* a;        /* [M, K] T, row stride lda (elements)                */
+  const void* wq;       /* packed by slm_w4_prepack                           */
+  const void* sz;       /* packed scale/zero table                            */
+  const int32_t* perm;  /* [K] act-order column gather for A, or NULL         */
+  const void* bias;     /* [N] T or NULL (added after accumulation)           */
+  void* c;              /* [M, N] T, row stride ldc                           */
+  int64_t M, K, N;
+  int64_t lda, ldc;
+  int64_t group_size;   /* K for per-channel (-1 in the checkpoint)           */
+  int32_t dtype;
+  int32_t reserved;
+  void* workspace;      /* split-K partials + act-order A copy                */
+  size_t workspace_bytes;
+} slm_w4_gemm_args;
+
+SLM_API size_t slm_w4a16_gemm_workspace_bytes(const slm_w4_gemm_args* a);
+SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream);
+
+/* Slow dequantise-to-dense helper (debug / parity): w_out [K, N] T.          */
+SLM_API int slm_w4_dequant(const void* wq, const void* sz, int64_t K, int64_t N,
+                           int64_t group_size, int32_t dtype, void* w_out, void* stream);
+
+/* ========================================================================== */
+/* 5. Glue ops of one decoder layer (SURVEY 8f "next" rows f1/f2).            */
+/*    replaces  kernel::apply_rotary_pos_emb  src/kernels/pos_embedding_      */
+/*              kernels.cu:35-121; kernel::rms_norm / rms_norm_residual       */
+/*              src/kernels/layernorm_kernels.cu:15,125;                      */
+/*              kernel::act_and_mul (silu) src/kernels/activation_kernels.cu  */
+/*              :84.                                                          */
+/* ========================================================================== */
+SLM_API int slm_rms_norm(void* out, const void* x, const void* weight, void* residual /* or NULL: in/out, x += residual first */,
+                         int64_t n_tokens, int64_t dim, float eps, int32_t dtype, void* stream);
+SLM_API int slm_rope_kv_append(void* q /* [T, n_heads, D] in place */, int64_t q_token_stride,
+                               void* k /* [T, n_kv_heads, D] in place */, int64_t k_token_stride,
+                               const void* v, int64_t v_token_stride,
+                               const int32_t* positions /* [T] */,
+                               const float* cos_sin /* [max_pos, rot_dim] fp32: cos | sin */,
+                               int32_t rot_dim, int32_t interleaved,
+                               const int32_t* slot_ids /* [T] or NULL (no append) */,
+                               void* key_cache, void* value_cache,
+                               int64_t n_tokens, int32_t n_heads, int32_t n_kv_heads,
+                               int32_t head_dim, int32_t dtype, void* stream);
+SLM_API int slm_silu_mul(void* out /* [T, d] */, const void* x /* [T, 2d]: gate | up */,
+                         int64_t n_tokens, int64_t d, int32_t dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLM_HIP_H_ */

@@ -1,0 +1,111 @@
+"""ctypes binding of libslm_hip.so (the C-ABI HIP kernel library, include/slm_hip.h).
+
+The product path FAILS LOUDLY when the HIP library is missing: there is no CPU or
+PyTorch fallback anywhere in scalellm_amd (the CPU oracle under oracle/ is test
+infrastructure and is never imported from here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libslm_hip.so")
+
+SLM_F16, SLM_BF16 = 0, 1
+SLM_W4_GPTQ, SLM_W4_AWQ = 0, 1
+
+
+class SlmError(RuntimeError):
+    pass
+
+
+class AttnArgs(C.Structure):
+    """struct slm_attn_args (include/slm_hip.h)."""
+    _fields_ = [
+        ("out", C.c_void_p), ("query", C.c_void_p), ("key_cache", C.c_void_p),
+        ("value_cache", C.c_void_p),
+        ("o_stride", C.c_int64 * 2), ("q_stride", C.c_int64 * 2), ("k_stride", C.c_int64 * 2),
+        ("v_stride", C.c_int64 * 2),
+        ("q_cu_lens", C.c_void_p), ("kv_cu_lens", C.c_void_p), ("block_table", C.c_void_p),
+        ("block_cu_lens", C.c_void_p), ("alibi_slopes", C.c_void_p),
+        ("dtype", C.c_int32), ("batch_size", C.c_int32), ("n_tokens", C.c_int32),
+        ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32), ("head_dim", C.c_int32),
+        ("block_size", C.c_int32), ("max_q_len", C.c_int32), ("max_kv_len", C.c_int32),
+        ("sm_scale", C.c_float), ("logits_soft_cap", C.c_float), ("sliding_window", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("num_splits", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class W4GemmArgs(C.Structure):
+    """struct slm_w4_gemm_args (include/slm_hip.h)."""
+    _fields_ = [
+        ("a", C.c_void_p), ("wq", C.c_void_p), ("sz", C.c_void_p), ("perm", C.c_void_p),
+        ("bias", C.c_void_p), ("c", C.c_void_p),
+        ("M", C.c_int64), ("K", C.c_int64), ("N", C.c_int64),
+        ("lda", C.c_int64), ("ldc", C.c_int64), ("group_size", C.c_int64),
+        ("dtype", C.c_int32), ("reserved", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libslm_hip.so or raise -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SlmError(
+            f"{LIB_PATH} not found: build it with `python -m scalellm_amd.build` "
+            "(hipcc --offload-arch=gfx950). scalellm_amd has no CPU / PyTorch fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.slm_status_string.restype = C.c_char_p
+    L.slm_status_string.argtypes = [C.c_int]
+    L.slm_version.restype = C.c_char_p
+    L.slm_paged_kv_varlen_mha.restype = C.c_int
+    L.slm_paged_kv_varlen_mha.argtypes = [C.POINTER(AttnArgs), C.c_void_p]
+    L.slm_paged_kv_varlen_mha_workspace_bytes.restype = C.c_size_t
+    L.slm_paged_kv_varlen_mha_workspace_bytes.argtypes = [C.POINTER(AttnArgs)]
+    L.slm_paged_kv_varlen_mha_auto_splits.restype = C.c_int32
+    L.slm_paged_kv_varlen_mha_auto_splits.argtypes = [C.POINTER(AttnArgs)]
+    L.slm_set_kv_cache.restype = C.c_int
+    L.slm_set_kv_cache.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                   C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                   C.c_int32, C.c_void_p]
+    for name, restype, argtypes in [
+        ("slm_w4_packed_weight_bytes", C.c_size_t, [C.c_int64, C.c_int64]),
+        ("slm_w4_packed_sz_bytes", C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
+        ("slm_w4_prepack", C.c_int,
+         [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+          C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+        ("slm_w4a16_gemm_workspace_bytes", C.c_size_t, [C.POINTER(W4GemmArgs)]),
+        ("slm_w4a16_gemm", C.c_int, [C.POINTER(W4GemmArgs), C.c_void_p]),
+        ("slm_w4_dequant", C.c_int,
+         [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
+          C.c_void_p]),
+        ("slm_rms_norm", C.c_int,
+         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float,
+          C.c_int32, C.c_void_p]),
+        ("slm_rope_kv_append", C.c_int,
+         [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+          C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+          C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+        ("slm_silu_mul", C.c_int,
+         [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    ]:
+        fn = getattr(L, name, None)
+        if fn is None:  # BRING-UP ONLY (removed once all entry points exist)
+            continue
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise SlmError(f"{what} failed: {lib().slm_status_string(rc).decode()} ({rc})")

@@ -1,0 +1,580 @@
+// attn.hip -- paged-KV varlen attention for gfx950 (CDNA4), hand-written HIP.
+//
+// Replaces llm::paged_kv_varlen_mha (reference src/kernels/attention/attn_api.cpp:14-73,
+// kernel src/kernels/attention/kernel/sm80_kernel_mha.cuh:174-335).  Designed from the
+// byte stream, not from the reference's 64x64 MMA tile:
+//
+//  * token-major work items: one workgroup = (query token, group of KV heads, q-head chunk,
+//    KV split).  Decode (q_len = 1), speculative verify (q_len = k+1) and prefill chunks are
+//    the same kernel with a per-token visible range [lo, hi) (causal diagonal
+//    kv_len - q_len + qi, sliding window) -- sm80_kernel_mha.cuh:255-262, common/mask.h:49-89.
+//  * the KV row of a slot, [n_kv_heads][head_dim] T, is contiguous: a wave's 64 lanes x 16 B
+//    load covers 1 KiB of it, i.e. 64/LPR (slot, kv-head) units with LPR = head_dim/8 lanes
+//    per unit.  When n_kv_heads >= 64/LPR the units of one load are adjacent heads of ONE slot
+//    (fully contiguous 1 KiB); otherwise they are heads x consecutive rows.
+//  * every lane group owns its (kv head, row phase): it keeps running (m, l, O[GC][8]) in
+//    registers for the GC query heads that share the kv head -- no cross-lane traffic in the
+//    loop except the LPR-lane DPP reduction of the q.k partial sums, no LDS on the data path
+//    (K/V are streamed once; nothing is reused across waves -- see DESIGN.md for why LDS
+//    staging is not used on the decode stream).
+//  * block table slice staged in LDS once per workgroup (one coalesced read), slot =
+//    tbl[row >> log2(bs)] + (row & (bs-1)) -- bit-exact with sm80_kernel_mha.cuh:146-152.
+//  * U-deep register ring of 16-B K/V loads per lane keeps >= 2*U KiB per wave in flight.
+//  * online softmax in base 2 (common/online_softmax.cuh:39-162 semantics), fp32 accumulate,
+//    exact conditional rescale (skipped when no running max moved in the wave).
+//  * split-KV partials (m, l, O) + combine kernel (math of attn_combine_kernel.cuh:14-21).
+#include "common.h"
+
+namespace slm {
+
+constexpr int ATTN_TBL_ENT = 2048;  // block-table entries staged per chunk (8 KiB LDS)
+constexpr float ATTN_M_INIT = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct AttnKParams {
+  void* out;
+  const void* q;
+  const void* kc;
+  const void* vc;
+  int64_t o_ts, o_hs, q_ts, q_hs, k_ss, k_hs, v_ss, v_hs;  // strides in elements
+  const int* q_cu;
+  const int* kv_cu;
+  const int* bt;
+  const int* bcu;
+  const float* alibi;
+  float* o_part;   // [n_tokens, n_heads, n_splits, head_dim]
+  float* ml_part;  // [n_tokens, n_heads, n_splits, 2]
+  int batch, n_tokens, n_heads, n_kv_heads, head_dim;
+  int block_shift, block_mask;
+  int group;      // q heads per kv head
+  int n_chunks;   // group / GC
+  int hpw_shift;  // log2(kv heads per wave-load)
+  int hgw_shift;  // log2(head groups per workgroup)
+  int nhgb;       // head-group blocks = n_kv_heads / (HPW * HGW)
+  int n_splits;
+  int window;
+  float scale_log2;  // (softcap > 0 ? softcap : sm_scale) * log2(e)
+  float pre_scale;   // sm_scale / softcap   (softcap > 0 only)
+  float softcap;
+};
+
+// tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e)); saturates correctly at +-inf, abs error ~1e-7
+// (the reference kernel uses tanh.approx: common/fast_math.h:30-60).
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float t = fast_exp2(x * (2.0f * LOG2E));
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + t);
+}
+
+template <bool NT>
+__device__ __forceinline__ u32x4 ld16(const void* p) {
+  if constexpr (NT)
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  else
+    return *reinterpret_cast<const u32x4*>(p);
+}
+
+template <typename T, int LPR, int GC, int U, bool NT, bool SC>
+__global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* tbl = reinterpret_cast<int*>(smem);
+  float* xch = reinterpret_cast<float*>(smem + ATTN_TBL_ENT * sizeof(int));
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+
+  int bid = blockIdx.x;
+  const int split = bid % p.n_splits;
+  bid /= p.n_splits;
+  const int chunk = bid % p.n_chunks;
+  bid /= p.n_chunks;
+  const int hgb = bid % p.nhgb;
+  const int tok = bid / p.nhgb;
+
+  // token -> sequence: q_cu[b] <= tok < q_cu[b+1]
+  int b;
+  {
+    int lo_b = 0, hi_b = p.batch;
+    while (lo_b < hi_b) {
+      const int mid = (lo_b + hi_b) >> 1;
+      if (p.q_cu[mid + 1] <= tok)
+        lo_b = mid + 1;
+      else
+        hi_b = mid;
+    }
+    b = lo_b;
+  }
+  if (b >= p.batch) return;  // padding token past q_cu[batch]
+
+  const int q_start = p.q_cu[b];
+  const int q_len = p.q_cu[b + 1] - q_start;
+  const int kv_len = p.kv_cu[b + 1] - p.kv_cu[b];
+  const int diag = kv_len - q_len + (tok - q_start);  // last visible kv index (causal)
+  const int hi = min(diag + 1, kv_len);
+  const int lo = (p.window >= 0) ? max(0, diag - p.window) : 0;
+
+  // lane / wave decomposition
+  constexpr int UPW = 64 / LPR;
+  const int g = lane / LPR;
+  const int sub = lane % LPR;
+  const int HPW = 1 << p.hpw_shift;
+  const int hsub = g & (HPW - 1);
+  const int rsub = g >> p.hpw_shift;
+  const int RPW = UPW >> p.hpw_shift;
+  const int HGW = 1 << p.hgw_shift;
+  const int hgw = wave & (HGW - 1);
+  const int rp = wave >> p.hgw_shift;
+  const int RP = nw >> p.hgw_shift;
+  const int RPI = RP * RPW;  // rows per workgroup iteration
+
+  const int kvh = (((hgb << p.hgw_shift) + hgw) << p.hpw_shift) + hsub;
+  const int qh0 = kvh * p.group + chunk * GC;
+  const bool act = (sub * 8) < p.head_dim;  // head_dim < 8*LPR leaves idle lanes (D = 40, 96)
+
+  // split range, aligned to RPI rows
+  const int len = max(hi - lo, 0);
+  int per = (len + p.n_splits - 1) / p.n_splits;
+  per = ((per + RPI - 1) / RPI) * RPI;
+  const int s_lo = lo + split * per;
+  const int s_hi = min(hi, s_lo + per);
+
+  // q fragment: GC heads x 8 dims (packed pairs)
+  uint32_t qv[GC][4];
+#pragma unroll
+  for (int h = 0; h < GC; ++h) {
+    u32x4 t = {0u, 0u, 0u, 0u};
+    if (act) {
+      const T* qp = reinterpret_cast<const T*>(p.q);
+      (void)qp;
+      const char* ptr = reinterpret_cast<const char*>(p.q) +
+                        2 * ((int64_t)tok * p.q_ts + (int64_t)(qh0 + h) * p.q_hs + sub * 8);
+      t = *reinterpret_cast<const u32x4*>(ptr);
+    }
+    qv[h][0] = t.x; qv[h][1] = t.y; qv[h][2] = t.z; qv[h][3] = t.w;
+  }
+  float slope2[GC];
+#pragma unroll
+  for (int h = 0; h < GC; ++h) slope2[h] = p.alibi ? p.alibi[qh0 + h] * LOG2E : 0.f;
+
+  float m[GC], l[GC], o[GC][8];
+#pragma unroll
+  for (int h = 0; h < GC; ++h) {
+    m[h] = ATTN_M_INIT;
+    l[h] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[h][j] = 0.f;
+  }
+
+  const int sub_ld = act ? sub : 0;  // idle lanes (q = 0) re-read dims 0..7: finite, never stored
+  const char* kbase = reinterpret_cast<const char*>(p.kc) + 2 * ((int64_t)kvh * p.k_hs + sub_ld * 8);
+  const char* vbase = reinterpret_cast<const char*>(p.vc) + 2 * ((int64_t)kvh * p.v_hs + sub_ld * 8);
+  // slot stride in bytes (< 2^32: plan_attn checks); slot >= 0 -> one v_mad_u64_u32 per address
+  const uint32_t k_sb = (uint32_t)(2 * p.k_ss), v_sb = (uint32_t)(2 * p.v_ss);
+  const int bcu0 = p.bcu[b];
+
+  u32x4 kr[U], vr[U];
+
+  for (int c_lo = s_lo; c_lo < s_hi;) {
+    const int blk0 = c_lo >> p.block_shift;
+    const int blk_end = min(((s_hi - 1) >> p.block_shift) + 1, blk0 + ATTN_TBL_ENT);
+    const int c_hi = min(s_hi, blk_end << p.block_shift);
+    __syncthreads();
+    for (int e = tid; e < blk_end - blk0; e += blockDim.x) tbl[e] = p.bt[bcu0 + blk0 + e];
+    __syncthreads();
+
+    const int wrow0 = c_lo + rp * RPW;  // wave-uniform first row of this wave in iteration 0
+    const int n_it = (c_hi - c_lo + RPI - 1) / RPI;
+
+    // Batched online softmax: U rows per lane group per loop trip, branch-free.
+    //  - loads are unconditional with clamped rows, so the loop body is straight-line code and
+    //    hipcc emits COUNTED s_waitcnt vmcnt(N): the K loads of the next batch are issued as
+    //    each K register is consumed, the V loads as each V register is consumed -> 2*U 16-B
+    //    loads per lane stay in flight across the loop back-edge;
+    //  - the running max is updated once per batch (one O rescale per U rows, no branch);
+    //  - past-the-end rows re-read the last valid row (cache hit) and are masked to -inf.
+    int slot_n[U];
+    auto slots_for = [&](int it0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = min(wrow0 + (it0 + u) * RPI + rsub, c_hi - 1);
+        slot_n[u] = tbl[(row >> p.block_shift) - blk0] + (row & p.block_mask);
+      }
+    };
+    slots_for(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) kr[u] = ld16<NT>(kbase + (uint64_t)(uint32_t)slot_n[u] * k_sb);
+#pragma unroll
+    for (int u = 0; u < U; ++u) vr[u] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u] * v_sb);
+    // compiler fence: keeps hipcc from sinking the prologue / next-batch loads into the
+    // consuming iteration (which would shorten the prefetch distance to < 1 batch)
+    asm volatile("" ::: "memory");
+
+    for (int it0 = 0; it0 < n_it; it0 += U) {
+      slots_for(it0 + U);  // next batch (clamped past the end)
+      float s[U][GC];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = wrow0 + (it0 + u) * RPI + rsub;
+        const bool valid = row < c_hi;
+        const u32x4 kk = kr[u];
+#pragma unroll
+        for (int h = 0; h < GC; ++h) {
+          float a = dot2<T>(kk.x, qv[h][0], 0.f);
+          a = dot2<T>(kk.y, qv[h][1], a);
+          a = dot2<T>(kk.z, qv[h][2], a);
+          a = dot2<T>(kk.w, qv[h][3], a);
+          a = group_sum<LPR>(a);
+          if constexpr (SC) a = fast_tanh(a * p.pre_scale);  // logits soft-cap (template: no cost when off)
+          a = a * p.scale_log2 + slope2[h] * (float)row;
+          s[u][h] = valid ? a : -INFINITY;
+        }
+        kr[u] = ld16<NT>(kbase + (uint64_t)(uint32_t)slot_n[u] * k_sb);
+        __builtin_amdgcn_sched_barrier(0);  // pin: next-batch K load issues right here
+      }
+#pragma unroll
+      for (int h = 0; h < GC; ++h) {
+        float mn = m[h];
+#pragma unroll
+        for (int u = 0; u < U; ++u) mn = fmaxf(mn, s[u][h]);
+        const float alpha = fast_exp2(m[h] - mn);
+        m[h] = mn;
+        l[h] *= alpha;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[h][j] *= alpha;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const u32x4 vv = vr[u];
+        float vf[8];
+        vf[0] = lo_f32<T>(vv.x); vf[1] = hi_f32<T>(vv.x);
+        vf[2] = lo_f32<T>(vv.y); vf[3] = hi_f32<T>(vv.y);
+        vf[4] = lo_f32<T>(vv.z); vf[5] = hi_f32<T>(vv.z);
+        vf[6] = lo_f32<T>(vv.w); vf[7] = hi_f32<T>(vv.w);
+#pragma unroll
+        for (int h = 0; h < GC; ++h) {
+          const float pr = fast_exp2(s[u][h] - m[h]);
+          l[h] += pr;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[h][j] = fmaf(pr, vf[j], o[h][j]);
+        }
+        vr[u] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u] * v_sb);
+        __builtin_amdgcn_sched_barrier(0);  // pin: next-batch V load issues right here
+      }
+      asm volatile("" ::: "memory");
+    }
+    c_lo = c_hi;
+  }
+
+  // ---- merge the row-phase lane groups of this wave (same kv head, different rows) ----
+  auto merge = [&](const float (&om)[GC], const float (&ol)[GC], const float (&oo)[GC][8]) {
+#pragma unroll
+    for (int h = 0; h < GC; ++h) {
+      const float mn = fmaxf(m[h], om[h]);
+      const float fa = fast_exp2(m[h] - mn);
+      const float fb = fast_exp2(om[h] - mn);
+      m[h] = mn;
+      l[h] = l[h] * fa + ol[h] * fb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[h][j] = o[h][j] * fa + oo[h][j] * fb;
+    }
+  };
+  for (int d = LPR << p.hpw_shift; d < 64; d <<= 1) {
+    float om[GC], ol[GC], oo[GC][8];
+#pragma unroll
+    for (int h = 0; h < GC; ++h) {
+      om[h] = __shfl_xor(m[h], d, 64);
+      ol[h] = __shfl_xor(l[h], d, 64);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) oo[h][j] = __shfl_xor(o[h][j], d, 64);
+    }
+    merge(om, ol, oo);
+  }
+
+  // ---- merge row-phase waves through LDS (sequential rounds; once per workgroup) ----
+  constexpr int NF = 10 * GC;  // floats of state per lane
+  float* my = xch + (size_t)hgw * NF * 64;
+  for (int r = 1; r < RP; ++r) {
+    __syncthreads();
+    if (rp == r) {
+#pragma unroll
+      for (int h = 0; h < GC; ++h) {
+        my[(h * 10 + 0) * 64 + lane] = m[h];
+        my[(h * 10 + 1) * 64 + lane] = l[h];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) my[(h * 10 + 2 + j) * 64 + lane] = o[h][j];
+      }
+    }
+    __syncthreads();
+    if (rp == 0) {
+      float om[GC], ol[GC], oo[GC][8];
+#pragma unroll
+      for (int h = 0; h < GC; ++h) {
+        om[h] = my[(h * 10 + 0) * 64 + lane];
+        ol[h] = my[(h * 10 + 1) * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) oo[h][j] = my[(h * 10 + 2 + j) * 64 + lane];
+      }
+      merge(om, ol, oo);
+    }
+  }
+
+  if (rp != 0 || rsub != 0 || !act) return;
+
+  if (p.n_splits == 1) {
+#pragma unroll
+    for (int h = 0; h < GC; ++h) {
+      const float inv = l[h] > 0.f ? 1.0f / l[h] : 0.f;
+      u32x4 r;
+      r.x = pack2<T>(o[h][0] * inv, o[h][1] * inv);
+      r.y = pack2<T>(o[h][2] * inv, o[h][3] * inv);
+      r.z = pack2<T>(o[h][4] * inv, o[h][5] * inv);
+      r.w = pack2<T>(o[h][6] * inv, o[h][7] * inv);
+      char* ptr = reinterpret_cast<char*>(p.out) +
+                  2 * ((int64_t)tok * p.o_ts + (int64_t)(qh0 + h) * p.o_hs + sub * 8);
+      *reinterpret_cast<u32x4*>(ptr) = r;
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < GC; ++h) {
+      const int64_t pi = ((int64_t)tok * p.n_heads + (qh0 + h)) * p.n_splits + split;
+      float* op = p.o_part + pi * p.head_dim + sub * 8;
+      *reinterpret_cast<f32x4*>(op) = f32x4{o[h][0], o[h][1], o[h][2], o[h][3]};
+      *reinterpret_cast<f32x4*>(op + 4) = f32x4{o[h][4], o[h][5], o[h][6], o[h][7]};
+      if (sub == 0) {
+        p.ml_part[pi * 2 + 0] = m[h];
+        p.ml_part[pi * 2 + 1] = l[h];
+      }
+    }
+  }
+}
+
+// out[tok, head, :] = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s   (one wave per (tok, head))
+template <typename T>
+__global__ void __launch_bounds__(256) attn_combine_kernel(const AttnKParams p) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (item >= (int64_t)p.n_tokens * p.n_heads) return;
+  const int tok = (int)(item / p.n_heads), head = (int)(item % p.n_heads);
+  const float* ml = p.ml_part + item * p.n_splits * 2;
+  float M = ATTN_M_INIT;
+  for (int s = 0; s < p.n_splits; ++s)
+    if (ml[2 * s + 1] > 0.f) M = fmaxf(M, ml[2 * s]);
+  float L = 0.f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* op = p.o_part + item * p.n_splits * p.head_dim;
+  for (int s = 0; s < p.n_splits; ++s) {
+    const float ls = ml[2 * s + 1];
+    if (!(ls > 0.f)) continue;
+    const float w = fast_exp2(ml[2 * s] - M);
+    L += w * ls;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = lane + 64 * i;
+      if (d < p.head_dim) acc[i] = fmaf(w, op[(int64_t)s * p.head_dim + d], acc[i]);
+    }
+  }
+  const float inv = L > 0.f ? 1.0f / L : 0.f;
+  uint16_t* optr =
+      reinterpret_cast<uint16_t*>(p.out) + (int64_t)tok * p.o_ts + (int64_t)head * p.o_hs;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = lane + 64 * i;
+    if (d < p.head_dim) optr[d] = pack1<T>(acc[i] * inv);
+  }
+}
+
+// ------------------------------- host side ------------------------------------------
+struct AttnPlan {
+  int lpr, gc, hpw_shift, hgw_shift, nhgb, n_chunks, nw, n_splits, u;
+  bool nt;
+  size_t lds_bytes;
+};
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
+  if (!a) return SLM_ERR_INVALID_ARG;
+  if (a->n_heads <= 0 || a->n_kv_heads <= 0 || a->n_heads % a->n_kv_heads) return SLM_ERR_INVALID_ARG;
+  if (a->head_dim <= 0 || a->head_dim > 256 || a->head_dim % 8) return SLM_ERR_UNSUPPORTED;
+  if (!is_pow2(a->block_size)) return SLM_ERR_INVALID_ARG;
+  if (a->dtype != SLM_F16 && a->dtype != SLM_BF16) return SLM_ERR_UNSUPPORTED;
+  if (a->k_stride[0] <= 0 || a->v_stride[0] <= 0 || a->k_stride[0] >= (1ll << 30) ||
+      a->v_stride[0] >= (1ll << 30))
+    return SLM_ERR_INVALID_ARG;
+  const int D = a->head_dim, G = a->n_heads / a->n_kv_heads;
+  pl->lpr = D <= 32 ? 4 : D <= 64 ? 8 : D <= 128 ? 16 : 32;
+  const int upw = 64 / pl->lpr;
+  pl->gc = (G % 8 == 0) ? 8 : (G % 4 == 0) ? 4 : (G % 2 == 0) ? 2 : 1;
+  pl->n_chunks = G / pl->gc;
+  int hpw = 1;
+  while (hpw * 2 <= upw && a->n_kv_heads % (hpw * 2) == 0) hpw *= 2;
+  pl->hpw_shift = ilog2(hpw);
+  const int nhg = a->n_kv_heads / hpw;
+  pl->nw = env_int("SLM_ATTN_NW", 8);
+  if (pl->nw != 1 && pl->nw != 2 && pl->nw != 4 && pl->nw != 8) pl->nw = 8;
+  // LDS: table + HGW x per-wave exchange state; keep table + exchange under the 64 KiB default dynamic-LDS limit
+  const size_t state = (size_t)10 * pl->gc * 64 * sizeof(float);
+  int hgw = 1;
+  const int hgw_cap = env_int("SLM_ATTN_HGW", pl->nw);
+  while (hgw * 2 <= pl->nw && hgw * 2 <= hgw_cap && nhg % (hgw * 2) == 0 &&
+         (size_t)(hgw * 2) * state <= 48 * 1024)
+    hgw *= 2;
+  pl->hgw_shift = ilog2(hgw);
+  pl->nhgb = nhg / hgw;
+  pl->lds_bytes = ATTN_TBL_ENT * sizeof(int) + (size_t)hgw * state;
+  const int rp = pl->nw / hgw, rpw = upw / hpw;
+  const int rpi = rp * rpw;
+  // split-KV heuristic: fill >= ~2 workgroups per CU, keep >= 64 iterations per split
+  int n_splits = a->num_splits;
+  if (n_splits <= 0) n_splits = env_int("SLM_ATTN_SPLITS", 0);
+  if (n_splits <= 0) {
+    const int64_t base = (int64_t)a->n_tokens * pl->nhgb * pl->n_chunks;
+    const int64_t target = 2 * 256;
+    int64_t want = (target + base - 1) / (base > 0 ? base : 1);
+    const int64_t max_by_len = (a->max_kv_len > 0 ? a->max_kv_len : 1) / (64 * rpi);
+    if (want > max_by_len) want = max_by_len;
+    if (want < 1) want = 1;
+    if (want > 256) want = 256;
+    n_splits = (int)want;
+  }
+  pl->n_splits = n_splits;
+  pl->u = env_int("SLM_ATTN_U", 4);
+  if (pl->u != 2 && pl->u != 4) pl->u = 4;
+  pl->nt = env_int("SLM_ATTN_NT", a->max_q_len <= 1 ? 1 : 0) != 0;
+  return SLM_OK;
+}
+
+template <typename T, int LPR, int GC>
+static void launch_token_kernel(const AttnKParams& kp, const AttnPlan& pl, int64_t grid,
+                                hipStream_t st) {
+  const dim3 g((unsigned)grid), blk(pl.nw * 64);
+#define SLM_LAUNCH(UU, NTT, SCC)                                                                \
+  hipLaunchKernelGGL((attn_token_kernel<T, LPR, GC, UU, NTT, SCC>), g, blk, pl.lds_bytes, st, kp)
+  if (kp.softcap > 0.f) {
+    SLM_LAUNCH(2, false, true);  // soft-cap models (Gemma-2 class): one tuned shape
+  } else if (pl.u == 2) {
+    if (pl.nt) SLM_LAUNCH(2, true, false); else SLM_LAUNCH(2, false, false);
+  } else {
+    if (pl.nt) SLM_LAUNCH(4, true, false); else SLM_LAUNCH(4, false, false);
+  }
+#undef SLM_LAUNCH
+}
+
+template <typename T, int LPR>
+static void dispatch_gc(const AttnKParams& kp, const AttnPlan& pl, int64_t grid, hipStream_t st) {
+  switch (pl.gc) {
+    case 8: launch_token_kernel<T, LPR, 8>(kp, pl, grid, st); break;
+    case 4: launch_token_kernel<T, LPR, 4>(kp, pl, grid, st); break;
+    case 2: launch_token_kernel<T, LPR, 2>(kp, pl, grid, st); break;
+    default: launch_token_kernel<T, LPR, 1>(kp, pl, grid, st); break;
+  }
+}
+
+template <typename T>
+static void dispatch_lpr(const AttnKParams& kp, const AttnPlan& pl, int64_t grid, hipStream_t st) {
+#ifdef SLM_ATTN_DEV_ONLY  // ISA-inspection builds: flagship instantiation only
+  launch_token_kernel<bf16_tag, 16, 4>(kp, pl, grid, st);
+  return;
+#else
+  switch (pl.lpr) {
+    case 4: dispatch_gc<T, 4>(kp, pl, grid, st); break;
+    case 8: dispatch_gc<T, 8>(kp, pl, grid, st); break;
+    case 16: dispatch_gc<T, 16>(kp, pl, grid, st); break;
+    default: dispatch_gc<T, 32>(kp, pl, grid, st); break;
+  }
+#endif
+}
+
+}  // namespace slm
+
+using namespace slm;
+
+extern "C" {
+
+SLM_API int32_t slm_paged_kv_varlen_mha_auto_splits(const slm_attn_args* a) {
+  AttnPlan pl;
+  if (plan_attn(a, &pl) != SLM_OK) return 0;
+  return pl.n_splits;
+}
+
+SLM_API size_t slm_paged_kv_varlen_mha_workspace_bytes(const slm_attn_args* a) {
+  AttnPlan pl;
+  if (plan_attn(a, &pl) != SLM_OK) return 0;
+  if (pl.n_splits <= 1) return 0;
+  return (size_t)a->n_tokens * a->n_heads * pl.n_splits * (a->head_dim + 2) * sizeof(float);
+}
+
+SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
+  AttnPlan pl;
+  int rc = plan_attn(a, &pl);
+  if (rc != SLM_OK) return rc;
+  if (a->n_tokens == 0 || a->batch_size == 0) return SLM_OK;
+  if (!a->out || !a->query || !a->key_cache || !a->value_cache || !a->q_cu_lens ||
+      !a->kv_cu_lens || !a->block_table || !a->block_cu_lens)
+    return SLM_ERR_INVALID_ARG;
+  if (a->n_tokens < 0 || a->batch_size < 0) return SLM_ERR_INVALID_ARG;
+  // 16-byte vector access on rows: base pointers and strides must keep 16-B alignment
+  if (!aligned16(a->out) || !aligned16(a->query) || !aligned16(a->key_cache) ||
+      !aligned16(a->value_cache))
+    return SLM_ERR_ALIGNMENT;
+  for (int i = 0; i < 2; ++i)
+    if (a->o_stride[i] % 8 || a->q_stride[i] % 8 || a->k_stride[i] % 8 || a->v_stride[i] % 8)
+      return SLM_ERR_ALIGNMENT;
+
+  AttnKParams kp;
+  kp.out = a->out; kp.q = a->query; kp.kc = a->key_cache; kp.vc = a->value_cache;
+  kp.o_ts = a->o_stride[0]; kp.o_hs = a->o_stride[1];
+  kp.q_ts = a->q_stride[0]; kp.q_hs = a->q_stride[1];
+  kp.k_ss = a->k_stride[0]; kp.k_hs = a->k_stride[1];
+  kp.v_ss = a->v_stride[0]; kp.v_hs = a->v_stride[1];
+  kp.q_cu = a->q_cu_lens; kp.kv_cu = a->kv_cu_lens;
+  kp.bt = a->block_table; kp.bcu = a->block_cu_lens;
+  kp.alibi = a->alibi_slopes;
+  kp.batch = a->batch_size; kp.n_tokens = a->n_tokens;
+  kp.n_heads = a->n_heads; kp.n_kv_heads = a->n_kv_heads; kp.head_dim = a->head_dim;
+  kp.block_shift = ilog2(a->block_size); kp.block_mask = a->block_size - 1;
+  kp.group = a->n_heads / a->n_kv_heads;
+  kp.n_chunks = pl.n_chunks; kp.hpw_shift = pl.hpw_shift; kp.hgw_shift = pl.hgw_shift;
+  kp.nhgb = pl.nhgb; kp.n_splits = pl.n_splits; kp.window = a->sliding_window;
+  if (a->logits_soft_cap > 0.f) {
+    // softmax(tanh(x*sm_scale/cap)*cap): mha_params.h:56-67
+    kp.softcap = a->logits_soft_cap;
+    kp.pre_scale = a->sm_scale / a->logits_soft_cap;
+    kp.scale_log2 = a->logits_soft_cap * LOG2E;
+  } else {
+    kp.softcap = 0.f; kp.pre_scale = 0.f; kp.scale_log2 = a->sm_scale * LOG2E;
+  }
+  kp.o_part = nullptr; kp.ml_part = nullptr;
+  if (pl.n_splits > 1) {
+    const size_t need =
+        (size_t)a->n_tokens * a->n_heads * pl.n_splits * (a->head_dim + 2) * sizeof(float);
+    if (!a->workspace || a->workspace_bytes < need) return SLM_ERR_WORKSPACE;
+    kp.o_part = reinterpret_cast<float*>(a->workspace);
+    kp.ml_part = kp.o_part + (size_t)a->n_tokens * a->n_heads * pl.n_splits * a->head_dim;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t grid = (int64_t)a->n_tokens * pl.nhgb * pl.n_chunks * pl.n_splits;
+  if (grid <= 0 || grid > 0x7fffffffLL) return SLM_ERR_INVALID_ARG;
+  if (a->dtype == SLM_BF16)
+    dispatch_lpr<bf16_tag>(kp, pl, grid, st);
+  else
+    dispatch_lpr<f16_tag>(kp, pl, grid, st);
+  rc = hip_check_launch();
+  if (rc != SLM_OK) return rc;
+  if (pl.n_splits > 1) {
+    const int64_t items = (int64_t)a->n_tokens * a->n_heads;
+    const dim3 g((unsigned)((items + 3) / 4)), blk(256);
+    if (a->dtype == SLM_BF16)
+      hipLaunchKernelGGL(attn_combine_kernel<bf16_tag>, g, blk, 0, st, kp);
+    else
+      hipLaunchKernelGGL(attn_combine_kernel<f16_tag>, g, blk, 0, st, kp);
+    rc = hip_check_launch();
+  }
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+// common.h -- shared device helpers for libslm_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "slm_hip.h"
+
+namespace slm {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+struct bf16_tag {};
+struct f16_tag {};
+
+// ---- packed 16-bit pair <-> fp32 ------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float lo_f32(uint32_t w);
+template <typename T>
+__device__ __forceinline__ float hi_f32(uint32_t w);
+
+template <>
+__device__ __forceinline__ float lo_f32<bf16_tag>(uint32_t w) {
+  return __builtin_bit_cast(float, w << 16);
+}
+template <>
+__device__ __forceinline__ float hi_f32<bf16_tag>(uint32_t w) {
+  return __builtin_bit_cast(float, w & 0xffff0000u);
+}
+template <>
+__device__ __forceinline__ float lo_f32<f16_tag>(uint32_t w) {
+  return (float)__builtin_bit_cast(f16x2_t, w)[0];
+}
+template <>
+__device__ __forceinline__ float hi_f32<f16_tag>(uint32_t w) {
+  return (float)__builtin_bit_cast(f16x2_t, w)[1];
+}
+
+// fp32 pair -> packed 16-bit pair, round-to-nearest-even
+template <typename T>
+__device__ __forceinline__ uint32_t pack2(float a, float b);
+template <>
+__device__ __forceinline__ uint32_t pack2<bf16_tag>(float a, float b) {
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <>
+__device__ __forceinline__ uint32_t pack2<f16_tag>(float a, float b) {
+  f16x2_t h = {(_Float16)a, (_Float16)b};
+  return __builtin_bit_cast(uint32_t, h);
+}
+
+template <typename T>
+__device__ __forceinline__ uint16_t pack1(float a) {
+  return (uint16_t)(pack2<T>(a, 0.f) & 0xffffu);
+}
+
+// acc += a.lo*b.lo + a.hi*b.hi  (v_dot2c_f32_bf16 / v_dot2c_f32_f16, fp32 accumulate)
+template <typename T>
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float acc);
+template <>
+__device__ __forceinline__ float dot2<bf16_tag>(uint32_t a, uint32_t b, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a),
+                                         __builtin_bit_cast(bf16x2_t, b), acc, false);
+}
+template <>
+__device__ __forceinline__ float dot2<f16_tag>(uint32_t a, uint32_t b, float acc) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, a), __builtin_bit_cast(f16x2_t, b),
+                                acc, false);
+}
+
+// ---- cross-lane (wave64) --------------------------------------------------------
+// DPP lane exchange inside a row of 16 lanes; full-rate VALU, no LDS traffic.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;     // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;     // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;  // i <-> 7-i inside each 8 lanes
+constexpr int DPP_ROW_MIRROR = 0x140;       // i <-> 15-i inside each 16 lanes
+
+// all-reduce sum across aligned groups of W lanes (W = 4, 8, 16, 32)
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+  v += dpp_f32<DPP_QUAD_XOR1>(v);
+  v += dpp_f32<DPP_QUAD_XOR2>(v);
+  if constexpr (W >= 8) v += dpp_f32<DPP_ROW_HALF_MIRROR>(v);
+  if constexpr (W >= 16) v += dpp_f32<DPP_ROW_MIRROR>(v);
+  if constexpr (W >= 32) v += __shfl_xor(v, 16, 64);
+  if constexpr (W >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+inline int hip_check_launch() { return hipGetLastError() == hipSuccess ? SLM_OK : SLM_ERR_LAUNCH; }
+
+inline bool is_pow2(int64_t x) { return x > 0 && (x & (x - 1)) == 0; }
+inline int ilog2(int64_t x) {
+  int r = 0;
+  while ((1ll << (r + 1)) <= x) ++r;
+  return r;
+}
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace slm

@@ -1,0 +1,81 @@
+// kv_cache.hip -- KV-cache append for gfx950.
+//
+// Replaces llm::kernel::set_kv_cache (reference src/kernels/kv_cache_kernels.cu:9-78):
+//   key_cache[slot_ids[t], h, d] = keys[t, h, d];  value_cache[...] = values[t, h, d]
+// A slot row [n_kv_heads, head_dim] is contiguous in the cache (src/memory/kv_cache.cpp:21-27),
+// so each token is one contiguous row copy: 16-byte vector copies, several tokens per
+// workgroup, keys/values may have different token strides (kv_cache_kernels.cu:54-58).
+#include "common.h"
+
+namespace slm {
+
+// VEC = bytes per lane access (16 or 2)
+template <int VEC>
+__global__ void __launch_bounds__(256) set_kv_cache_kernel(
+    const int* __restrict__ slot_ids, const char* __restrict__ keys,
+    const char* __restrict__ values, int64_t k_stride_b, int64_t v_stride_b,
+    char* __restrict__ key_cache, char* __restrict__ value_cache, int64_t n_tokens,
+    int row_bytes, int lanes_per_row, int rows_per_block) {
+  const int r = threadIdx.x / lanes_per_row;
+  const int c = threadIdx.x % lanes_per_row;
+  const int64_t tok = (int64_t)blockIdx.x * rows_per_block + r;
+  if (r >= rows_per_block || tok >= n_tokens) return;
+  const int64_t slot = slot_ids[tok];
+  const char* ks = keys + tok * k_stride_b;
+  const char* vs = values + tok * v_stride_b;
+  char* kd = key_cache + slot * (int64_t)row_bytes;
+  char* vd = value_cache + slot * (int64_t)row_bytes;
+  for (int off = c * VEC; off < row_bytes; off += lanes_per_row * VEC) {
+    if constexpr (VEC == 16) {
+      const u32x4 kx = *reinterpret_cast<const u32x4*>(ks + off);
+      const u32x4 vx = *reinterpret_cast<const u32x4*>(vs + off);
+      *reinterpret_cast<u32x4*>(kd + off) = kx;
+      *reinterpret_cast<u32x4*>(vd + off) = vx;
+    } else {
+      const uint16_t kx = *reinterpret_cast<const uint16_t*>(ks + off);
+      const uint16_t vx = *reinterpret_cast<const uint16_t*>(vs + off);
+      *reinterpret_cast<uint16_t*>(kd + off) = kx;
+      *reinterpret_cast<uint16_t*>(vd + off) = vx;
+    }
+  }
+}
+
+}  // namespace slm
+
+using namespace slm;
+
+extern "C" SLM_API int slm_set_kv_cache(const int32_t* slot_ids, const void* keys,
+                                        const void* values, int64_t k_token_stride,
+                                        int64_t v_token_stride, void* key_cache,
+                                        void* value_cache, int64_t n_tokens, int32_t n_kv_heads,
+                                        int32_t head_dim, int32_t dtype, void* stream) {
+  if (n_tokens == 0) return SLM_OK;
+  if (!slot_ids || !keys || !values || !key_cache || !value_cache) return SLM_ERR_INVALID_ARG;
+  if (n_tokens < 0 || n_kv_heads <= 0 || head_dim <= 0) return SLM_ERR_INVALID_ARG;
+  if (dtype != SLM_F16 && dtype != SLM_BF16) return SLM_ERR_UNSUPPORTED;
+  const int64_t row_bytes64 = (int64_t)n_kv_heads * head_dim * 2;
+  if (row_bytes64 > (1 << 24)) return SLM_ERR_INVALID_ARG;
+  const int row_bytes = (int)row_bytes64;
+  const int64_t ksb = k_token_stride * 2, vsb = v_token_stride * 2;
+  const bool vec16 = (row_bytes % 16 == 0) && (ksb % 16 == 0) && (vsb % 16 == 0) &&
+                     aligned16(keys) && aligned16(values) && aligned16(key_cache) &&
+                     aligned16(value_cache);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int vec = vec16 ? 16 : 2;
+  int lanes = (row_bytes + vec - 1) / vec;
+  if (lanes > 256) lanes = 256;
+  // round lanes-per-row up to a power of two <= 256 so rows do not straddle oddly
+  int lpr = 1;
+  while (lpr < lanes) lpr <<= 1;
+  const int rows_per_block = 256 / lpr;
+  const unsigned grid = (unsigned)((n_tokens + rows_per_block - 1) / rows_per_block);
+  if (vec16)
+    hipLaunchKernelGGL(set_kv_cache_kernel<16>, dim3(grid), dim3(256), 0, st, slot_ids,
+                       (const char*)keys, (const char*)values, ksb, vsb, (char*)key_cache,
+                       (char*)value_cache, n_tokens, row_bytes, lpr, rows_per_block);
+  else
+    hipLaunchKernelGGL(set_kv_cache_kernel<2>, dim3(grid), dim3(256), 0, st, slot_ids,
+                       (const char*)keys, (const char*)values, ksb, vsb, (char*)key_cache,
+                       (char*)value_cache, n_tokens, row_bytes, lpr, rows_per_block);
+  return hip_check_launch();
+}

@@ -1,0 +1,124 @@
+"""CPU tests: the oracle (oracle/slm_oracle.c) against the golden vectors generated from the
+REFERENCE's own Python references (tests/golden/make_golden.py) and the reference's GPTQ
+fixture.  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import helpers
+
+
+ATTN_CASES = helpers.load_attn_cases()
+
+
+@pytest.mark.parametrize("name", sorted(ATTN_CASES))
+def test_paged_attention_matches_reference_python(name):
+    c = ATTN_CASES[name]
+    out = oracle.paged_attn(c["q_f32"], c["k_f32"], c["v_f32"], c["q_cu_lens"], c["kv_cu_lens"],
+                            c["block_table"], c["block_cu_lens"], c["block_size"], c["sm_scale"],
+                            c["softcap"], c["window"], c["alibi"])
+    # reference python computes in fp32 then casts to the (16-bit) query dtype
+    tol = 1e-2 if c["is_bf16"] else 2e-3
+    np.testing.assert_allclose(out, c["out"], rtol=tol, atol=tol)
+    # and the un-rounded comparison is much tighter on average
+    assert np.abs(out - c["out"]).mean() < (2e-3 if c["is_bf16"] else 3e-4)
+
+
+def test_block_table_slot_arithmetic_bit_exact():
+    # Sequence::kv_cache_slots (request/sequence.cpp:303-317): slot = block_id*bs + i%bs
+    rng = np.random.default_rng(0)
+    for bs in (1, 2, 8, 16, 64):
+        kv_lens = rng.integers(1, 200, size=5)
+        nblk = [(k + bs - 1) // bs for k in kv_lens]
+        ids = rng.permutation(np.arange(1, sum(nblk) + 3))[:sum(nblk)]
+        table = (ids * bs).astype(np.int32)
+        bcu = np.concatenate([[0], np.cumsum(nblk)]).astype(np.int32)
+        kcu = np.concatenate([[0], np.cumsum(kv_lens)]).astype(np.int32)
+        got = oracle.all_slots(table, bcu, kcu, bs)
+        exp, off = [], 0
+        for b, k in enumerate(kv_lens):
+            blocks = ids[off:off + nblk[b]]
+            off += nblk[b]
+            exp.extend(int(blocks[i // bs]) * bs + i % bs for i in range(k))
+        assert np.array_equal(got, np.asarray(exp, dtype=np.int32))
+
+
+def test_online_softmax_form_matches_einsum_form():
+    # mha_cpu_test.cpp:62-86: tiled online softmax vs plain softmax, fp32, tol 1e-4
+    rng = np.random.default_rng(1)
+    for (ql, kl, h, hkv, d) in [(1, 37, 4, 4, 32), (13, 64, 8, 2, 64), (5, 5, 6, 1, 128)]:
+        q = rng.standard_normal((ql, h, d), dtype=np.float32)
+        k = rng.standard_normal((kl, hkv, d), dtype=np.float32)
+        v = rng.standard_normal((kl, hkv, d), dtype=np.float32)
+        online = oracle.mha_online(q, k, v)
+        table = np.arange(0, kl, dtype=np.int32)  # block_size 1, identity paging
+        dense = oracle.paged_attn(q, k, v, [0, ql], [0, kl], table, [0, kl], 1, d ** -0.5)
+        np.testing.assert_allclose(online, dense, rtol=1e-4, atol=1e-4)
+
+
+def test_combine_matches_unsplit():
+    rng = np.random.default_rng(2)
+    kl, h, d = 96, 4, 64
+    q = rng.standard_normal((1, h, d), dtype=np.float32)
+    k = rng.standard_normal((kl, h, d), dtype=np.float32)
+    v = rng.standard_normal((kl, h, d), dtype=np.float32)
+    full = oracle.paged_attn(q, k, v, [0, 1], [0, kl], np.arange(kl, dtype=np.int32), [0, kl], 1,
+                             d ** -0.5)
+    splits = 3
+    o_part = np.zeros((h, splits, d), np.float32)
+    ml = np.zeros((h, splits, 2), np.float32)
+    for s in range(splits):
+        ks, vs = k[s * 32:(s + 1) * 32], v[s * 32:(s + 1) * 32]
+        sc = np.einsum("hd,khd->hk", q[0], ks) * d ** -0.5 * np.log2(np.e)
+        m = sc.max(-1)
+        p = np.exp2(sc - m[:, None])
+        ml[:, s, 0], ml[:, s, 1] = m, p.sum(-1)
+        o_part[:, s] = np.einsum("hk,khd->hd", p, vs)
+    got = oracle.combine(o_part, ml)
+    np.testing.assert_allclose(got, full[0], rtol=1e-5, atol=1e-5)
+
+
+QUANT = helpers.load_npz_groups("quant_cases.npz")
+
+
+@pytest.mark.parametrize("name", sorted(n for n in QUANT if n.startswith("gptq")))
+def test_gptq_dequant_matches_reference_python(name):
+    c = QUANT[name]
+    gs = int(c["group_size"][0])
+    g_idx = c["g_idx"] if int(c["act_order"][0]) else None
+    w = oracle.gptq_dequant(c["qweight"], c["qzeros"], c["scales"].astype(np.float32), gs, g_idx)
+    np.testing.assert_array_equal(w, c["w"])  # integer unpack + one fp32 multiply: exact
+
+
+@pytest.mark.parametrize("name", sorted(n for n in QUANT if n.startswith("awq")))
+def test_awq_dequant_matches_reference_python(name):
+    c = QUANT[name]
+    w = oracle.awq_dequant(c["qweight"], c["qzeros"], c["scales"].astype(np.float32),
+                           int(c["group_size"][0]))
+    np.testing.assert_array_equal(w, c["w"])
+
+
+def test_gptq_small_reference_fixture():
+    # qlinear_impl_test.cpp:10-22: construct_weights with and without g_idx agree on
+    # data/gptq_small.safetensors; plus the value computed with the reference's python unpackers
+    z = np.load(helpers.GOLDEN + "/gptq_small.npz")
+    sc = z["scales"].astype(np.float32)
+    w_gidx = oracle.gptq_dequant(z["qweight"], z["qzeros"], sc, 128, z["g_idx"])
+    w_plain = oracle.gptq_dequant(z["qweight"], z["qzeros"], sc, 128, None)
+    np.testing.assert_array_equal(w_gidx, w_plain)
+    np.testing.assert_array_equal(w_gidx, z["w"])
+
+
+def test_set_kv_cache_and_gemm():
+    rng = np.random.default_rng(3)
+    keys = rng.integers(0, 65535, size=(7, 2, 8)).astype(np.uint16)
+    vals = rng.integers(0, 65535, size=(7, 2, 8)).astype(np.uint16)
+    kc = np.zeros((20, 2, 8), np.uint16)
+    vc = np.zeros((20, 2, 8), np.uint16)
+    slots = rng.permutation(20)[:7].astype(np.int32)
+    oracle.set_kv_cache(slots, keys, vals, kc, vc)
+    assert np.array_equal(kc[slots], keys) and np.array_equal(vc[slots], vals)
+    assert kc.sum() == keys.sum()
+    a = rng.standard_normal((5, 33), dtype=np.float32)
+    w = rng.standard_normal((33, 17), dtype=np.float32)
+    np.testing.assert_allclose(oracle.gemm_f32(a, w), a @ w, rtol=1e-5, atol=1e-5)
