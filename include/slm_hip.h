@@ -194,15 +194,22 @@ SLM_API int slm_w4_dequant(const void* wq, const void* sz, int64_t K, int64_t N,
 /*              kernel::act_and_mul (silu) src/kernels/activation_kernels.cu  */
 /*              :84.                                                          */
 /* ========================================================================== */
-SLM_API int slm_rms_norm(void* out, const void* x, const void* weight, void* residual /* or NULL: in/out, x += residual first */,
+/* residual != NULL: x := x + residual (fp32), residual := T(x), then normalise
+ * (rms_norm_residual, src/layers/normalization.h:42-52). */
+SLM_API int slm_rms_norm(void* out, const void* x, const void* weight, void* residual,
                          int64_t n_tokens, int64_t dim, float eps, int32_t dtype, void* stream);
+/* Rotary embedding applied in place to q and k, fused with the KV append that always follows it
+ * (src/layers/attention/attention.cpp:36-42).  cos_sin row = [cos(rot/2) | sin(rot/2)] per
+ * position (the reference cache layout, pos_embedding_kernels.cu:41: [max_pos, 2, rot/2]), either
+ * in the activation dtype (as RotaryEmbeddingKernel builds it, pos_embedding.cpp:195-196) or
+ * fp32.  cos_sin == NULL skips the rotation (alibi models); slot_ids == NULL skips the append. */
 SLM_API int slm_rope_kv_append(void* q /* [T, n_heads, D] in place */, int64_t q_token_stride,
                                void* k /* [T, n_kv_heads, D] in place */, int64_t k_token_stride,
-                               const void* v, int64_t v_token_stride,
+                               const void* v /* [T, n_kv_heads, D] */, int64_t v_token_stride,
                                const int32_t* positions /* [T] */,
-                               const float* cos_sin /* [max_pos, rot_dim] fp32: cos | sin */,
+                               const void* cos_sin /* [max_pos, rot_dim] */, int32_t cos_sin_is_f32,
                                int32_t rot_dim, int32_t interleaved,
-                               const int32_t* slot_ids /* [T] or NULL (no append) */,
+                               const int32_t* slot_ids /* [T] or NULL */,
                                void* key_cache, void* value_cache,
                                int64_t n_tokens, int32_t n_heads, int32_t n_kv_heads,
                                int32_t head_dim, int32_t dtype, void* stream);

@@ -92,14 +92,12 @@ def lib() -> C.CDLL:
           C.c_int32, C.c_void_p]),
         ("slm_rope_kv_append", C.c_int,
          [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
-          C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
-          C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+          C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+          C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
         ("slm_silu_mul", C.c_int,
          [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     ]:
-        fn = getattr(L, name, None)
-        if fn is None:  # BRING-UP ONLY (removed once all entry points exist)
-            continue
+        fn = getattr(L, name)  # AttributeError here = library/header mismatch: fail loudly
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = L

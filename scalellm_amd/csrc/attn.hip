@@ -349,38 +349,82 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
   }
 }
 
-// out[tok, head, :] = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s   (one wave per (tok, head))
+// out[tok, head, :] = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s   (one wave per (tok, head)).
+// Latency-oriented: lanes first own SPLITS (one (m, l) pair each, wave-reduced to M and L, the
+// weights parked in LDS), then own DIMS (4 consecutive floats per lane, several split phases
+// per wave) with 4 independent 16-B loads in flight per lane -- no per-split dependent chain.
+constexpr int COMBINE_MAX_SPLITS = 256;
+
 template <typename T>
-__global__ void __launch_bounds__(256) attn_combine_kernel(const AttnKParams p) {
+__global__ void __launch_bounds__(256) attn_combine_kernel(const AttnKParams p, int lps_shift) {
+  __shared__ float wsm[4][COMBINE_MAX_SPLITS];
   const int lane = threadIdx.x & 63;
-  const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wv = threadIdx.x >> 6;
+  const int64_t item = (int64_t)blockIdx.x * 4 + wv;
   if (item >= (int64_t)p.n_tokens * p.n_heads) return;
   const int tok = (int)(item / p.n_heads), head = (int)(item % p.n_heads);
   const float* ml = p.ml_part + item * p.n_splits * 2;
+  float mreg[4], lreg[4];
   float M = ATTN_M_INIT;
-  for (int s = 0; s < p.n_splits; ++s)
-    if (ml[2 * s + 1] > 0.f) M = fmaxf(M, ml[2 * s]);
-  float L = 0.f;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const float* op = p.o_part + item * p.n_splits * p.head_dim;
-  for (int s = 0; s < p.n_splits; ++s) {
-    const float ls = ml[2 * s + 1];
-    if (!(ls > 0.f)) continue;
-    const float w = fast_exp2(ml[2 * s] - M);
-    L += w * ls;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int d = lane + 64 * i;
-      if (d < p.head_dim) acc[i] = fmaf(w, op[(int64_t)s * p.head_dim + d], acc[i]);
-    }
-  }
-  const float inv = L > 0.f ? 1.0f / L : 0.f;
-  uint16_t* optr =
-      reinterpret_cast<uint16_t*>(p.out) + (int64_t)tok * p.o_ts + (int64_t)head * p.o_hs;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int d = lane + 64 * i;
-    if (d < p.head_dim) optr[d] = pack1<T>(acc[i] * inv);
+    const int s = lane + 64 * i;
+    mreg[i] = ATTN_M_INIT;
+    lreg[i] = 0.f;
+    if (s < p.n_splits) {
+      const float2 v = *reinterpret_cast<const float2*>(ml + 2 * s);
+      mreg[i] = v.x;
+      lreg[i] = v.y;
+    }
+    if (lreg[i] > 0.f) M = fmaxf(M, mreg[i]);
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) M = fmaxf(M, __shfl_xor(M, d, 64));
+  float L = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float w = lreg[i] > 0.f ? fast_exp2(mreg[i] - M) : 0.f;
+    L += w * lreg[i];
+    wsm[wv][lane + 64 * i] = w;
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) L += __shfl_xor(L, d, 64);
+  __builtin_amdgcn_wave_barrier();  // wsm row is wave-private; LDS ops of one wave are ordered
+
+  const int LPS = 1 << lps_shift;      // lanes per split (>= head_dim/4)
+  const int phase = lane >> lps_shift;  // split phase of this lane
+  const int n_phase = 64 >> lps_shift;
+  const int d0 = (lane & (LPS - 1)) * 4;
+  const bool actd = d0 < p.head_dim;
+  const float* op = p.o_part + item * p.n_splits * p.head_dim + d0;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (actd) {
+    int s = phase;
+    for (; s + 3 * n_phase < p.n_splits; s += 4 * n_phase) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(op + (int64_t)s * p.head_dim);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(op + (int64_t)(s + n_phase) * p.head_dim);
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(op + (int64_t)(s + 2 * n_phase) * p.head_dim);
+      const f32x4 a3 = *reinterpret_cast<const f32x4*>(op + (int64_t)(s + 3 * n_phase) * p.head_dim);
+      acc += wsm[wv][s] * a0 + wsm[wv][s + n_phase] * a1 + wsm[wv][s + 2 * n_phase] * a2 +
+             wsm[wv][s + 3 * n_phase] * a3;
+    }
+    for (; s < p.n_splits; s += n_phase)
+      acc += wsm[wv][s] * *reinterpret_cast<const f32x4*>(op + (int64_t)s * p.head_dim);
+  }
+  for (int d = LPS; d < 64; d <<= 1) {
+    acc.x += __shfl_xor(acc.x, d, 64);
+    acc.y += __shfl_xor(acc.y, d, 64);
+    acc.z += __shfl_xor(acc.z, d, 64);
+    acc.w += __shfl_xor(acc.w, d, 64);
+  }
+  if (phase == 0 && actd) {
+    const float inv = L > 0.f ? 1.0f / L : 0.f;
+    u32x2 r;
+    r.x = pack2<T>(acc.x * inv, acc.y * inv);
+    r.y = pack2<T>(acc.z * inv, acc.w * inv);
+    char* optr = reinterpret_cast<char*>(p.out) +
+                 2 * ((int64_t)tok * p.o_ts + (int64_t)head * p.o_hs + d0);
+    *reinterpret_cast<u32x2*>(optr) = r;
   }
 }
 
@@ -414,33 +458,39 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
   while (hpw * 2 <= upw && a->n_kv_heads % (hpw * 2) == 0) hpw *= 2;
   pl->hpw_shift = ilog2(hpw);
   const int nhg = a->n_kv_heads / hpw;
-  pl->nw = env_int("SLM_ATTN_NW", 8);
-  if (pl->nw != 1 && pl->nw != 2 && pl->nw != 4 && pl->nw != 8) pl->nw = 8;
-  // LDS: table + HGW x per-wave exchange state; keep table + exchange under the 64 KiB default dynamic-LDS limit
+  // Launch shape tuned on MI355X (tools/sweep_attn.py, profiles/attn_sweep_r1.md): 4 waves per
+  // workgroup, ~256 workgroups per launch, >= 64 KV rows per split.
+  pl->nw = env_int("SLM_ATTN_NW", 4);
+  if (pl->nw != 1 && pl->nw != 2 && pl->nw != 4 && pl->nw != 8) pl->nw = 4;
   const size_t state = (size_t)10 * pl->gc * 64 * sizeof(float);
-  int hgw = 1;
-  const int hgw_cap = env_int("SLM_ATTN_HGW", pl->nw);
-  while (hgw * 2 <= pl->nw && hgw * 2 <= hgw_cap && nhg % (hgw * 2) == 0 &&
-         (size_t)(hgw * 2) * state <= 48 * 1024)
-    hgw *= 2;
+  const int64_t target_wgs = 256;
+  const int64_t max_by_len = (a->max_kv_len > 64 ? a->max_kv_len : 64) / 64;
+  int forced_splits = a->num_splits > 0 ? a->num_splits : env_int("SLM_ATTN_SPLITS", 0);
+  int hgw_cap = env_int("SLM_ATTN_HGW", pl->nw);
+  int hgw = 1, n_splits = 1;
+  for (int pass = 0; pass < 2; ++pass) {
+    // LDS: table + HGW x per-wave exchange state, kept under the 64 KiB default dynamic limit
+    hgw = 1;
+    while (hgw * 2 <= pl->nw && hgw * 2 <= hgw_cap && nhg % (hgw * 2) == 0 &&
+           (size_t)(hgw * 2) * state <= 48 * 1024)
+      hgw *= 2;
+    const int64_t base = (int64_t)a->n_tokens * (nhg / hgw) * pl->n_chunks;
+    int64_t want = (target_wgs + base - 1) / (base > 0 ? base : 1);
+    if (want > max_by_len) want = max_by_len;
+    if (want < 1) want = 1;
+    if (want > COMBINE_MAX_SPLITS) want = COMBINE_MAX_SPLITS;
+    n_splits = forced_splits > 0 ? forced_splits : (int)want;
+    // tiny batches: if the grid is still short of one workgroup per CU, stop sharing a
+    // workgroup between head groups (doubles / quadruples the workgroup count)
+    if (pass == 0 && base * n_splits < target_wgs && hgw > 1 && getenv("SLM_ATTN_HGW") == nullptr)
+      hgw_cap = 1;
+    else
+      break;
+  }
   pl->hgw_shift = ilog2(hgw);
   pl->nhgb = nhg / hgw;
   pl->lds_bytes = ATTN_TBL_ENT * sizeof(int) + (size_t)hgw * state;
-  const int rp = pl->nw / hgw, rpw = upw / hpw;
-  const int rpi = rp * rpw;
-  // split-KV heuristic: fill >= ~2 workgroups per CU, keep >= 64 iterations per split
-  int n_splits = a->num_splits;
-  if (n_splits <= 0) n_splits = env_int("SLM_ATTN_SPLITS", 0);
-  if (n_splits <= 0) {
-    const int64_t base = (int64_t)a->n_tokens * pl->nhgb * pl->n_chunks;
-    const int64_t target = 2 * 256;
-    int64_t want = (target + base - 1) / (base > 0 ? base : 1);
-    const int64_t max_by_len = (a->max_kv_len > 0 ? a->max_kv_len : 1) / (64 * rpi);
-    if (want > max_by_len) want = max_by_len;
-    if (want < 1) want = 1;
-    if (want > 256) want = 256;
-    n_splits = (int)want;
-  }
+  if (n_splits > COMBINE_MAX_SPLITS) n_splits = COMBINE_MAX_SPLITS;
   pl->n_splits = n_splits;
   pl->u = env_int("SLM_ATTN_U", 4);
   if (pl->u != 2 && pl->u != 4) pl->u = 4;
@@ -568,10 +618,12 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
   if (pl.n_splits > 1) {
     const int64_t items = (int64_t)a->n_tokens * a->n_heads;
     const dim3 g((unsigned)((items + 3) / 4)), blk(256);
+    int lps_shift = 3;  // lanes per split: power of two >= head_dim / 4
+    while ((4 << lps_shift) < a->head_dim) ++lps_shift;
     if (a->dtype == SLM_BF16)
-      hipLaunchKernelGGL(attn_combine_kernel<bf16_tag>, g, blk, 0, st, kp);
+      hipLaunchKernelGGL(attn_combine_kernel<bf16_tag>, g, blk, 0, st, kp, lps_shift);
     else
-      hipLaunchKernelGGL(attn_combine_kernel<f16_tag>, g, blk, 0, st, kp);
+      hipLaunchKernelGGL(attn_combine_kernel<f16_tag>, g, blk, 0, st, kp, lps_shift);
     rc = hip_check_launch();
   }
   return rc;

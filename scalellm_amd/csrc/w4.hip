@@ -1,0 +1,559 @@
+// w4.hip -- int4-weight x fp16/bf16-activation GEMM for gfx950 (CDNA4): prepack, dequant, GEMM.
+//
+// Replaces the reference's vendored Marlin path (src/kernels/quantization/marlin/*:
+// marlin::gptq_gemm gptq_gemm.cu:585-710, marlin::gptq_repack gptq_repack.cu:252,
+// marlin::awq_repack awq_repack.cu:191, permute_cols_kernel gptq_gemm.cu:69-118) with a layout
+// and a kernel designed for the CDNA4 matrix core (v_mfma_f32_32x32x16_{bf16,f16}, wave64):
+//
+//  packed weights  wq[N/32][K/64][64 lanes][4] u32: lane l, word j = the 8 weights
+//      n = 32*nt + (l & 31),  k = 64*kt + 16*j + 8*(l >> 5) + e,  e = 0..7
+//    i.e. exactly the B-operand fragment of one 32x32x16 MFMA, so a wave's 16-B/lane load is one
+//    contiguous KiB that feeds 4 MFMA k-steps with NO shuffle and NO LDS round trip.  Nibbles are
+//    pair-interleaved (bit 4i = e 2i, bit 16+4i = e 2i+1) so `(w >> 4i) & 0x000F000F | magic`
+//    yields a packed 16-bit pair directly (v_and_or_b32).
+//  scale/zero table sz[G][N] u32 = { scale : T, magic+zero : T }  (magic = 128 bf16 / 1024 fp16;
+//    the sum is exact in T), one 4-byte load per (group, column).
+//  dequant: w = (q - z) * s, bit-identical to "dequantise in T then multiply" (reference
+//    marlin/numeric_conversion.h:19-62,121-166,232-240: magic-number int4 -> T, sub zp, scale):
+//      fp16: v_pk_add_f16 (exact) + v_pk_mul_f16 (RN);  bf16 (no packed bf16 VALU on gfx950):
+//      fp32 fma(128+q, s, -(128+z)s) is exact, then v_cvt_pk_bf16_f32 (RN).
+//  GEMM: C[M,N] = A[M,K] . W[K,N]; activations are the MFMA A operand (rows = tokens), staged
+//    per 128-deep K chunk through XOR-swizzled LDS (conflict-free ds_read_b128); weights go
+//    HBM -> registers -> dequant -> MFMA B operand; fp32 accumulate; optional split-K with fp32
+//    partials + reduce (bias added after the reduction, as qlinear_awq_marlin_impl.cpp:357-363).
+#include "common.h"
+
+namespace slm {
+
+// ------------------------------------------------------------------------------------------
+// unpack helpers (shared by the GEMM and the debug dequant kernel: one code path to test)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct W4Dq;
+
+template <>
+struct W4Dq<bf16_tag> {
+  float s, c;
+  __device__ __forceinline__ explicit W4Dq(uint32_t sz) {
+    s = __builtin_bit_cast(float, sz << 16);
+    const float zm = __builtin_bit_cast(float, sz & 0xffff0000u);  // 128 + zero, exact
+    c = -zm * s;                                                    // <= 16 significant bits: exact
+  }
+  // 8 nibbles -> 4 packed bf16 pairs, element order e = 0..7
+  __device__ __forceinline__ void word(uint32_t w, uint32_t (&out)[4]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t t = ((w >> (4 * i)) & 0x000F000Fu) | 0x43004300u;  // (128+q_lo, 128+q_hi)
+      const float lo = __builtin_bit_cast(float, t << 16);
+      const float hi = __builtin_bit_cast(float, t & 0xffff0000u);
+      out[i] = pack2<bf16_tag>(fmaf(lo, s, c), fmaf(hi, s, c));  // (q - z) * s exact, then RN
+    }
+  }
+};
+
+template <>
+struct W4Dq<f16_tag> {
+  f16x2_t s2, nzm2;
+  __device__ __forceinline__ explicit W4Dq(uint32_t sz) {
+    const f16x2_t v = __builtin_bit_cast(f16x2_t, sz);
+    s2 = f16x2_t{v[0], v[0]};
+    nzm2 = f16x2_t{-v[1], -v[1]};  // -(1024 + zero)
+  }
+  __device__ __forceinline__ void word(uint32_t w, uint32_t (&out)[4]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t t = ((w >> (4 * i)) & 0x000F000Fu) | 0x64006400u;  // (1024+q_lo, 1024+q_hi)
+      const f16x2_t d = __builtin_bit_cast(f16x2_t, t) + nzm2;          // q - z, exact
+      out[i] = __builtin_bit_cast(uint32_t, d * s2);                    // RN
+    }
+  }
+};
+
+__device__ __forceinline__ int awq_pos(int col_in_word) {  // [0,2,4,6,1,3,5,7] interleave
+  return (col_in_word >> 1) + 4 * (col_in_word & 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// prepack: checkpoint formats -> wq / sz   (bit-exact integer work)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) w4_prepack_weight_kernel(
+    int format, const uint32_t* __restrict__ qweight, const int* __restrict__ perm, int64_t K,
+    int64_t N, uint32_t* __restrict__ wq) {
+  const int64_t widx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (widx >= N * K / 8) return;
+  const int j = (int)(widx & 3);
+  const int lane = (int)((widx >> 2) & 63);
+  const int64_t tile = widx >> 8;
+  const int64_t kt = tile % (K / 64), nt = tile / (K / 64);
+  const int64_t n = nt * 32 + (lane & 31);
+  const int64_t kb = kt * 64 + j * 16 + (lane >> 5) * 8;
+  uint32_t out = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int64_t k = perm ? (int64_t)perm[kb + e] : kb + e;
+    uint32_t q;
+    if (format == SLM_W4_GPTQ)
+      q = (qweight[(k / 8) * N + n] >> (4 * (k % 8))) & 0xFu;
+    else
+      q = (qweight[k * (N / 8) + n / 8] >> (4 * awq_pos((int)(n % 8)))) & 0xFu;
+    const int pos = (e >> 1) + 4 * (e & 1);
+    out |= q << (4 * pos);
+  }
+  wq[widx] = out;
+}
+
+__global__ void __launch_bounds__(256) w4_prepack_sz_kernel(
+    int format, const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales, int64_t G,
+    int64_t N, int dtype, uint32_t* __restrict__ sz) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= G * N) return;
+  const int64_t g = idx / N, n = idx % N;
+  const uint32_t zw = qzeros[g * (N / 8) + n / 8];
+  uint32_t z;
+  if (format == SLM_W4_GPTQ)
+    z = ((zw >> (4 * (n % 8))) & 0xFu) + 1u;  // qlinear_impl.cpp:45 (zeros.add_(1))
+  else
+    z = (zw >> (4 * awq_pos((int)(n % 8)))) & 0xFu;
+  const uint32_t zm = (dtype == SLM_BF16 ? 0x4300u : 0x6400u) + z;  // 128 + z  /  1024 + z
+  sz[idx] = (uint32_t)scales[idx] | (zm << 16);
+}
+
+// debug / parity: dense W[K, N] in T from the packed form (uses W4Dq = the GEMM's dequant)
+template <typename T>
+__global__ void __launch_bounds__(256) w4_dequant_kernel(const uint32_t* __restrict__ wq,
+                                                         const uint32_t* __restrict__ sz, int64_t K,
+                                                         int64_t N, int64_t gs,
+                                                         uint16_t* __restrict__ w_out) {
+  const int64_t widx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (widx >= N * K / 8) return;
+  const int j = (int)(widx & 3);
+  const int lane = (int)((widx >> 2) & 63);
+  const int64_t tile = widx >> 8;
+  const int64_t kt = tile % (K / 64), nt = tile / (K / 64);
+  const int64_t n = nt * 32 + (lane & 31);
+  const int64_t kb = kt * 64 + j * 16 + (lane >> 5) * 8;
+  const W4Dq<T> dq(sz[(kb / gs) * N + n]);
+  uint32_t o[4];
+  dq.word(wq[widx], o);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    w_out[(kb + 2 * i) * N + n] = (uint16_t)(o[i] & 0xffffu);
+    w_out[(kb + 2 * i + 1) * N + n] = (uint16_t)(o[i] >> 16);
+  }
+}
+
+// A'[m, k] = A[m, perm[k]]  (act-order; reference permute_cols_kernel gptq_gemm.cu:69-118)
+__global__ void __launch_bounds__(256) w4_permute_cols_kernel(const uint16_t* __restrict__ a,
+                                                              const int* __restrict__ perm,
+                                                              int64_t M, int64_t K, int64_t lda,
+                                                              uint16_t* __restrict__ out) {
+  const int64_t m = blockIdx.y;
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < K;
+       k += (int64_t)gridDim.x * blockDim.x)
+    out[m * K + k] = a[m * lda + perm[k]];
+}
+
+// ------------------------------------------------------------------------------------------
+// GEMM
+// ------------------------------------------------------------------------------------------
+struct GemmKParams {
+  const void* a;
+  const uint32_t* wq;
+  const uint32_t* sz;
+  const void* bias;
+  void* c;
+  float* part;  // [split_k][M][N] fp32 (split_k > 1)
+  int64_t M, K, N, lda, ldc;
+  int gs_shift;      // log2(group_size) (group_size >= 128 handled via k >> gs_shift too)
+  int n_chunks;      // K / 128
+  int split_k;
+  int chunks_per_split;
+  int n_mblocks, n_nblocks;
+};
+
+template <typename T>
+struct Mfma;
+template <>
+struct Mfma<bf16_tag> {
+  typedef bf16x8_t frag;
+  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Mfma<f16_tag> {
+  typedef f16x8_t frag;
+  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+constexpr int W4_KC = 128;  // K chunk (LDS row = 256 B = 16 x 16-B slots, XOR-swizzled by row&15)
+
+// MT: 32-token tiles per workgroup (BM = 32*MT); NTW: 32-column tiles per wave (BN = 128*NTW);
+// NG: scale groups per 128-deep chunk (1 for group >= 128, 2 for 64, 4 for 32)
+template <typename T, int MT, int NTW, int NG>
+__global__ void __launch_bounds__(256) w4a16_gemm_kernel(const GemmKParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename Mfma<T>::frag frag_t;
+  constexpr int BM = 32 * MT;
+  constexpr int A_LD = MT * 2;            // 16-B slots staged per thread per chunk
+  constexpr int BUF_BYTES = BM * 256;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  const int nb = bid % p.n_nblocks;
+  bid /= p.n_nblocks;
+  const int mb = bid % p.n_mblocks;
+  const int ks = bid / p.n_mblocks;
+
+  const int64_t m0 = (int64_t)mb * BM;
+  const int c0 = ks * p.chunks_per_split;
+  const int c1 = min(p.n_chunks, c0 + p.chunks_per_split);
+
+  // this wave's column tiles (clamped: out-of-range tiles compute on the last valid tile, no store)
+  const int64_t n_tiles = p.N / 32;
+  int64_t ntile[NTW];
+  bool nvalid[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int64_t g = ((int64_t)nb * 4 + wave) * NTW + t;
+    nvalid[t] = g < n_tiles;
+    ntile[t] = nvalid[t] ? g : n_tiles - 1;
+  }
+  const int64_t ktiles = p.K / 64;
+
+  f32x16 acc[NTW][MT];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][m][r] = 0.f;
+
+  // ---- A staging: thread -> (row, slot) pairs, global 16-B loads, swizzled LDS writes ----
+  const char* abase = reinterpret_cast<const char*>(p.a);
+  u32x4 areg[A_LD];
+  auto a_load = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 4, slot = idx & 15;
+      const int64_t m = m0 + row;
+      const int64_t mc = m < p.M ? m : p.M - 1;  // clamp (rows >= M are never stored)
+      areg[i] = *reinterpret_cast<const u32x4*>(abase + 2 * (mc * p.lda + (int64_t)c * W4_KC + slot * 8));
+    }
+  };
+  auto a_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx >> 4, slot = idx & 15;
+      *reinterpret_cast<u32x4*>(smem + buf * BUF_BYTES + row * 256 + ((slot ^ (row & 15)) << 4)) = areg[i];
+    }
+  };
+
+  // ---- weight / scale loads for one chunk ----
+  u32x4 wreg[NTW][2];
+  uint32_t szreg[NTW][NG];
+  auto w_load = [&](int c) {
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const uint32_t* wp = p.wq + ((ntile[t] * ktiles + (int64_t)c * 2) * 64 + lane) * 4;
+      wreg[t][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp));
+      wreg[t][1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + 256));
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int64_t grp = ((int64_t)c * W4_KC + g * (W4_KC / NG)) >> p.gs_shift;
+        szreg[t][g] = p.sz[grp * p.N + ntile[t] * 32 + (lane & 31)];
+      }
+    }
+  };
+
+  if (c0 < c1) {
+    a_load(c0);
+    w_load(c0);
+    a_store(0);
+  }
+  __syncthreads();
+
+  const int mrow = lane & 31, kh = lane >> 5;
+  for (int c = c0; c < c1; ++c) {
+    const int buf = (c - c0) & 1;
+    // dequantise this chunk's weights into MFMA B fragments
+    frag_t bfrag[NTW][8];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) {
+        const W4Dq<T> dq(szreg[t][w8 * NG / 8]);
+        uint32_t o[4];
+        const u32x4 wv = wreg[t][w8 >> 2];
+        const uint32_t word = (w8 & 3) == 0 ? wv.x : (w8 & 3) == 1 ? wv.y : (w8 & 3) == 2 ? wv.z : wv.w;
+        dq.word(word, o);
+        const u32x4 packed = {o[0], o[1], o[2], o[3]};
+        bfrag[t][w8] = __builtin_bit_cast(frag_t, packed);
+      }
+    }
+    // prefetch the next chunk (clamped at the end: a redundant reload, keeps the loop branch-free)
+    const int cn = min(c + 1, c1 - 1);
+    w_load(cn);
+    a_load(cn);
+    // MFMAs: A fragments from LDS (conflict-free swizzled ds_read_b128), reused across NTW tiles
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int row = m * 32 + mrow;
+        const int slot = k8 * 2 + kh;
+        const u32x4 av = *reinterpret_cast<const u32x4*>(smem + buf * BUF_BYTES + row * 256 +
+                                                         ((slot ^ (row & 15)) << 4));
+        const frag_t af = __builtin_bit_cast(frag_t, av);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t][m] = Mfma<T>::run(af, bfrag[t][k8], acc[t][m]);
+      }
+    }
+    a_store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    if (!nvalid[t]) continue;
+    const int64_t n = ntile[t] * 32 + (lane & 31);
+    float bv = 0.f;
+    if (p.split_k == 1 && p.bias) {
+      const uint16_t braw = reinterpret_cast<const uint16_t*>(p.bias)[n];
+      bv = lo_f32<T>((uint32_t)braw);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.M) {
+          if (p.split_k == 1)
+            reinterpret_cast<uint16_t*>(p.c)[row * p.ldc + n] = pack1<T>(acc[t][m][r] + bv);
+          else
+            p.part[((int64_t)ks * p.M + row) * p.N + n] = acc[t][m][r];
+        }
+      }
+    }
+  }
+}
+
+// C[m, n] = T( sum_s part[s][m][n] + bias[n] )
+template <typename T>
+__global__ void __launch_bounds__(256) w4_splitk_reduce_kernel(const float* __restrict__ part,
+                                                               const void* __restrict__ bias,
+                                                               void* __restrict__ c, int64_t M,
+                                                               int64_t N, int64_t ldc, int split_k) {
+  const int64_t idx4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // 4 columns per thread
+  if (idx4 * 4 >= M * N) return;
+  const int64_t m = (idx4 * 4) / N, n = (idx4 * 4) % N;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < split_k; ++k)
+    s += *reinterpret_cast<const f32x4*>(part + ((int64_t)k * M + m) * N + n);
+  if (bias) {
+    const u32x2 b = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(bias) + n);
+    s.x += lo_f32<T>(b.x); s.y += hi_f32<T>(b.x);
+    s.z += lo_f32<T>(b.y); s.w += hi_f32<T>(b.y);
+  }
+  u32x2 r;
+  r.x = pack2<T>(s.x, s.y);
+  r.y = pack2<T>(s.z, s.w);
+  *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(c) + m * ldc + n) = r;
+}
+
+// ------------------------------- host side ------------------------------------------
+struct GemmPlan {
+  int mt, ntw, ng, split_k, chunks_per_split, n_mblocks, n_nblocks;
+  size_t lds_bytes, part_bytes, aperm_bytes;
+};
+
+static int w4_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
+  if (!a) return SLM_ERR_INVALID_ARG;
+  if (a->M < 0 || a->K <= 0 || a->N <= 0) return SLM_ERR_INVALID_ARG;
+  if (a->dtype != SLM_F16 && a->dtype != SLM_BF16) return SLM_ERR_UNSUPPORTED;
+  if (a->K % W4_KC || a->N % 32) return SLM_ERR_UNSUPPORTED;  // reference: K%128, N%64
+  const int64_t gs = a->group_size;
+  if (!(gs == 32 || gs == 64 || (gs >= 128 && gs % 128 == 0 && is_pow2(gs)) || gs == a->K))
+    return SLM_ERR_UNSUPPORTED;
+  if (a->K % gs) return SLM_ERR_UNSUPPORTED;
+  pl->ng = gs == 32 ? 4 : gs == 64 ? 2 : 1;
+  int mt = a->M <= 32 ? 1 : a->M <= 64 ? 2 : 4;
+  mt = w4_env_int("SLM_W4_MT", mt);
+  if (mt != 1 && mt != 2 && mt != 4) mt = 4;
+  int ntw = w4_env_int("SLM_W4_NTW", 1);
+  if (ntw != 1 && ntw != 2) ntw = 1;
+  if (mt == 4) ntw = 1;
+  pl->mt = mt;
+  pl->ntw = ntw;
+  const int bm = 32 * mt, bn = 128 * ntw;
+  pl->n_mblocks = (int)((a->M + bm - 1) / bm);
+  pl->n_nblocks = (int)((a->N + bn - 1) / bn);
+  const int n_chunks = (int)(a->K / W4_KC);
+  const int64_t tiles = (int64_t)pl->n_mblocks * pl->n_nblocks;
+  int split_k = w4_env_int("SLM_W4_SPLITK", 0);
+  if (split_k <= 0) {
+    // fill ~2 workgroups per CU, keep >= 4 chunks (512 of K) per split
+    int64_t want = (512 + tiles - 1) / (tiles > 0 ? tiles : 1);
+    const int64_t cap = n_chunks / 4 > 0 ? n_chunks / 4 : 1;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    split_k = (int)want;
+  }
+  if (split_k > n_chunks) split_k = n_chunks;
+  pl->chunks_per_split = (n_chunks + split_k - 1) / split_k;
+  pl->split_k = (n_chunks + pl->chunks_per_split - 1) / pl->chunks_per_split;
+  pl->lds_bytes = (size_t)2 * bm * 256;
+  pl->part_bytes = pl->split_k > 1 ? (size_t)pl->split_k * a->M * a->N * sizeof(float) : 0;
+  pl->aperm_bytes = a->perm ? (((size_t)a->M * a->K * 2 + 255) & ~(size_t)255) : 0;
+  return SLM_OK;
+}
+
+template <typename T, int MT, int NTW>
+static void launch_gemm_ng(const GemmKParams& kp, const GemmPlan& pl, hipStream_t st) {
+  const dim3 grid((unsigned)((int64_t)pl.n_nblocks * pl.n_mblocks * pl.split_k)), blk(256);
+  switch (pl.ng) {
+    case 4: hipLaunchKernelGGL((w4a16_gemm_kernel<T, MT, NTW, 4>), grid, blk, pl.lds_bytes, st, kp); break;
+    case 2: hipLaunchKernelGGL((w4a16_gemm_kernel<T, MT, NTW, 2>), grid, blk, pl.lds_bytes, st, kp); break;
+    default: hipLaunchKernelGGL((w4a16_gemm_kernel<T, MT, NTW, 1>), grid, blk, pl.lds_bytes, st, kp); break;
+  }
+}
+
+template <typename T>
+static void launch_gemm(const GemmKParams& kp, const GemmPlan& pl, hipStream_t st) {
+  if (pl.mt == 4) launch_gemm_ng<T, 4, 1>(kp, pl, st);
+  else if (pl.mt == 2 && pl.ntw == 2) launch_gemm_ng<T, 2, 2>(kp, pl, st);
+  else if (pl.mt == 2) launch_gemm_ng<T, 2, 1>(kp, pl, st);
+  else if (pl.ntw == 2) launch_gemm_ng<T, 1, 2>(kp, pl, st);
+  else launch_gemm_ng<T, 1, 1>(kp, pl, st);
+}
+
+}  // namespace slm
+
+using namespace slm;
+
+extern "C" {
+
+SLM_API size_t slm_w4_packed_weight_bytes(int64_t K, int64_t N) {
+  if (K <= 0 || N <= 0 || K % 64 || N % 32) return 0;
+  return (size_t)K * N / 2;
+}
+
+SLM_API size_t slm_w4_packed_sz_bytes(int64_t K, int64_t N, int64_t group_size) {
+  if (K <= 0 || N <= 0 || group_size <= 0 || K % group_size) return 0;
+  return (size_t)(K / group_size) * N * sizeof(uint32_t);
+}
+
+SLM_API int slm_w4_prepack(int32_t format, const int32_t* qweight, const int32_t* qzeros,
+                           const void* scales, const int32_t* perm, int64_t K, int64_t N,
+                           int64_t group_size, int32_t dtype, void* wq_out, void* sz_out,
+                           void* stream) {
+  if (!qweight || !qzeros || !scales || !wq_out || !sz_out) return SLM_ERR_INVALID_ARG;
+  if (format != SLM_W4_GPTQ && format != SLM_W4_AWQ) return SLM_ERR_UNSUPPORTED;
+  if (dtype != SLM_F16 && dtype != SLM_BF16) return SLM_ERR_UNSUPPORTED;
+  if (K <= 0 || N <= 0 || K % 64 || N % 32 || group_size <= 0 || K % group_size)
+    return SLM_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t words = K * N / 8;
+  hipLaunchKernelGGL(w4_prepack_weight_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0,
+                     st, format, reinterpret_cast<const uint32_t*>(qweight), perm, K, N,
+                     reinterpret_cast<uint32_t*>(wq_out));
+  int rc = hip_check_launch();
+  if (rc != SLM_OK) return rc;
+  const int64_t G = K / group_size;
+  hipLaunchKernelGGL(w4_prepack_sz_kernel, dim3((unsigned)((G * N + 255) / 256)), dim3(256), 0, st,
+                     format, reinterpret_cast<const uint32_t*>(qzeros),
+                     reinterpret_cast<const uint16_t*>(scales), G, N, dtype,
+                     reinterpret_cast<uint32_t*>(sz_out));
+  return hip_check_launch();
+}
+
+SLM_API int slm_w4_dequant(const void* wq, const void* sz, int64_t K, int64_t N,
+                           int64_t group_size, int32_t dtype, void* w_out, void* stream) {
+  if (!wq || !sz || !w_out) return SLM_ERR_INVALID_ARG;
+  if (K <= 0 || N <= 0 || K % 64 || N % 32 || group_size < 16 || K % group_size)
+    return SLM_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t words = K * N / 8;
+  const dim3 grid((unsigned)((words + 255) / 256)), blk(256);
+  if (dtype == SLM_BF16)
+    hipLaunchKernelGGL(w4_dequant_kernel<bf16_tag>, grid, blk, 0, st, (const uint32_t*)wq,
+                       (const uint32_t*)sz, K, N, group_size, (uint16_t*)w_out);
+  else if (dtype == SLM_F16)
+    hipLaunchKernelGGL(w4_dequant_kernel<f16_tag>, grid, blk, 0, st, (const uint32_t*)wq,
+                       (const uint32_t*)sz, K, N, group_size, (uint16_t*)w_out);
+  else
+    return SLM_ERR_UNSUPPORTED;
+  return hip_check_launch();
+}
+
+SLM_API size_t slm_w4a16_gemm_workspace_bytes(const slm_w4_gemm_args* a) {
+  GemmPlan pl;
+  if (plan_gemm(a, &pl) != SLM_OK) return 0;
+  return pl.part_bytes + pl.aperm_bytes;
+}
+
+SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream) {
+  GemmPlan pl;
+  int rc = plan_gemm(a, &pl);
+  if (rc != SLM_OK) return rc;
+  if (a->M == 0) return SLM_OK;
+  if (!a->a || !a->wq || !a->sz || !a->c) return SLM_ERR_INVALID_ARG;
+  if (!aligned16(a->a) || !aligned16(a->wq) || a->lda % 8 || a->lda < a->K || a->ldc < a->N)
+    return SLM_ERR_ALIGNMENT;
+  if ((pl.part_bytes + pl.aperm_bytes) > 0 &&
+      (!a->workspace || a->workspace_bytes < pl.part_bytes + pl.aperm_bytes))
+    return SLM_ERR_WORKSPACE;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+  GemmKParams kp;
+  kp.a = a->a; kp.lda = a->lda;
+  if (a->perm) {  // act-order: gather the activation columns once (gptq_gemm.cu:69-118)
+    uint16_t* ap = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a->workspace) + pl.part_bytes);
+    const unsigned gx = (unsigned)((a->K + 255) / 256);
+    hipLaunchKernelGGL(w4_permute_cols_kernel, dim3(gx > 64 ? 64 : gx, (unsigned)a->M), dim3(256), 0,
+                       st, reinterpret_cast<const uint16_t*>(a->a), a->perm, a->M, a->K, a->lda, ap);
+    rc = hip_check_launch();
+    if (rc != SLM_OK) return rc;
+    kp.a = ap; kp.lda = a->K;
+  }
+  kp.wq = reinterpret_cast<const uint32_t*>(a->wq);
+  kp.sz = reinterpret_cast<const uint32_t*>(a->sz);
+  kp.bias = a->bias; kp.c = a->c;
+  kp.part = pl.split_k > 1 ? reinterpret_cast<float*>(a->workspace) : nullptr;
+  kp.M = a->M; kp.K = a->K; kp.N = a->N; kp.ldc = a->ldc;
+  // per-channel scales (group_size == K, not necessarily a power of two): every k maps to group 0
+  kp.gs_shift = (a->group_size == a->K) ? 30 : ilog2(a->group_size);
+  kp.n_chunks = (int)(a->K / W4_KC);
+  kp.split_k = pl.split_k; kp.chunks_per_split = pl.chunks_per_split;
+  kp.n_mblocks = pl.n_mblocks; kp.n_nblocks = pl.n_nblocks;
+  if (a->dtype == SLM_BF16) launch_gemm<bf16_tag>(kp, pl, st);
+  else launch_gemm<f16_tag>(kp, pl, st);
+  rc = hip_check_launch();
+  if (rc != SLM_OK) return rc;
+  if (pl.split_k > 1) {
+    const int64_t n4 = a->M * a->N / 4;
+    const dim3 grid((unsigned)((n4 + 255) / 256)), blk(256);
+    if (a->dtype == SLM_BF16)
+      hipLaunchKernelGGL(w4_splitk_reduce_kernel<bf16_tag>, grid, blk, 0, st, kp.part, a->bias, a->c,
+                         a->M, a->N, a->ldc, pl.split_k);
+    else
+      hipLaunchKernelGGL(w4_splitk_reduce_kernel<f16_tag>, grid, blk, 0, st, kp.part, a->bias, a->c,
+                         a->M, a->N, a->ldc, pl.split_k);
+    rc = hip_check_launch();
+  }
+  return rc;
+}
+
+}  // extern "C"

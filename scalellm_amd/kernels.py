@@ -178,3 +178,187 @@ def set_kv_cache(slot_ids: torch.Tensor, keys: torch.Tensor, values: torch.Tenso
                              keys.stride(0), values.stride(0), key_cache.data_ptr(),
                              value_cache.data_ptr(), keys.size(0), keys.size(1), keys.size(2),
                              _dtype_code(keys), _stream()), "slm_set_kv_cache")
+
+
+# ---------------------------------------------------------------------------------------
+# int4 (AWQ / GPTQ) prepack + GEMM
+# ---------------------------------------------------------------------------------------
+class PackedW4:
+    """Weights in libslm_hip's MFMA-native int4 layout (see include/slm_hip.h section 3).
+
+    Produced once per layer at load time from the CHECKPOINT tensors, exactly where the
+    reference repacks into the Marlin layout on first forward
+    (qlinear_awq_marlin_impl.cpp:99-125,232-235; qlinear_gptq_marlin_impl.cpp:41-71,181-184).
+    """
+
+    def __init__(self, wq, sz, perm, K, N, group_size, dtype):
+        self.wq, self.sz, self.perm = wq, sz, perm
+        self.K, self.N, self.group_size, self.dtype = K, N, group_size, dtype
+
+
+def _prepack(fmt: int, qweight, qzeros, scales, perm, K, N, group_size) -> PackedW4:
+    L = _lib.lib()
+    _require_gpu(qweight, qzeros, scales, perm)
+    for t in (qweight, qzeros):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise SlmError("qweight / qzeros must be contiguous int32")
+    if not scales.is_contiguous():
+        raise SlmError("scales must be contiguous [n_groups, N]")
+    gs = K if group_size in (-1, 0) else int(group_size)
+    if K % gs or tuple(scales.shape) != (K // gs, N) or tuple(qzeros.shape) != (K // gs, N // 8):
+        raise SlmError(f"scales/qzeros shapes do not match K={K} N={N} group_size={gs}")
+    nb_w, nb_sz = L.slm_w4_packed_weight_bytes(K, N), L.slm_w4_packed_sz_bytes(K, N, gs)
+    if nb_w == 0 or nb_sz == 0:
+        raise SlmError(f"unsupported int4 shape K={K} N={N} group_size={gs} (need K%64, N%32)")
+    wq = torch.empty(nb_w // 4, dtype=torch.int32, device=qweight.device)
+    sz = torch.empty(nb_sz // 4, dtype=torch.int32, device=qweight.device)
+    if perm is not None and (perm.dtype != torch.int32 or not perm.is_contiguous()):
+        raise SlmError("perm must be contiguous int32 [K]")
+    check(L.slm_w4_prepack(fmt, qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
+                           perm.data_ptr() if perm is not None else None, K, N, gs,
+                           _dtype_code(scales), wq.data_ptr(), sz.data_ptr(), _stream()),
+          "slm_w4_prepack")
+    return PackedW4(wq, sz, perm, K, N, gs, scales.dtype)
+
+
+def awq_repack(qweight: torch.Tensor,  # [K, N/8] int32, AWQ interleave
+               qzeros: torch.Tensor,   # [G, N/8] int32, AWQ interleave
+               scales: torch.Tensor,   # [G, N] fp16/bf16
+               group_size: int) -> PackedW4:
+    """Mirror of marlin::awq_repack (+ the host-side zero/scale permutes of
+    qlinear_awq_marlin_impl.cpp:34-125), from the AWQ checkpoint format."""
+    K, N = qweight.size(0), qweight.size(1) * 8
+    return _prepack(_lib.SLM_W4_AWQ, qweight, qzeros, scales, None, K, N, group_size)
+
+
+def gptq_repack(qweight: torch.Tensor,  # [K/8, N] int32
+                qzeros: torch.Tensor,   # [G, N/8] int32 (zero = stored + 1)
+                scales: torch.Tensor,   # [G, N]
+                group_size: int,
+                g_idx: Optional[torch.Tensor] = None) -> PackedW4:
+    """Mirror of marlin::gptq_repack (+ qlinear_gptq_marlin_impl.cpp:41-71): act-order
+    checkpoints (g_idx not monotone) are handled like the reference: rows sorted by group
+    (perm = argsort(g_idx)), the activation columns gathered by the same perm at GEMM time."""
+    K, N = qweight.size(0) * 8, qweight.size(1)
+    gs = K if group_size in (-1, 0) else int(group_size)
+    perm = None
+    if g_idx is not None and g_idx.numel() > 0:
+        if g_idx.numel() != K:
+            raise SlmError("g_idx must have K entries")
+        trivial = torch.arange(K, device=g_idx.device, dtype=torch.int64) // gs
+        if not torch.equal(g_idx.to(torch.int64), trivial):
+            perm64 = torch.argsort(g_idx.to(torch.int64), stable=True)
+            # the kernel needs whole groups after sorting (every group has group_size rows)
+            if not torch.equal(g_idx.to(torch.int64)[perm64], trivial):
+                raise SlmError("act-order g_idx with uneven groups is not supported")
+            perm = perm64.to(torch.int32).contiguous()
+    return _prepack(_lib.SLM_W4_GPTQ, qweight, qzeros, scales, perm, K, N, gs)
+
+
+def _gemm_args(a, packed: PackedW4, c, bias) -> W4GemmArgs:
+    _require_gpu(a, c, bias)
+    if a.dim() != 2 or c.dim() != 2 or a.stride(1) != 1 or c.stride(1) != 1:
+        raise SlmError("A [M, K] and C [M, N] must be 2-D with contiguous rows")
+    if a.size(1) != packed.K or c.size(1) != packed.N or a.size(0) != c.size(0):
+        raise SlmError("GEMM shape mismatch")
+    if a.dtype != packed.dtype or c.dtype != packed.dtype:
+        raise SlmError("activation / output dtype must match the prepacked scales dtype")
+    g = W4GemmArgs()
+    g.a, g.wq, g.sz = a.data_ptr(), packed.wq.data_ptr(), packed.sz.data_ptr()
+    g.perm = packed.perm.data_ptr() if packed.perm is not None else None
+    g.bias = bias.data_ptr() if bias is not None else None
+    g.c = c.data_ptr()
+    g.M, g.K, g.N = a.size(0), packed.K, packed.N
+    g.lda, g.ldc = a.stride(0), c.stride(0)
+    g.group_size = packed.group_size
+    g.dtype = _dtype_code(a)
+    g.workspace, g.workspace_bytes = None, 0
+    return g
+
+
+def gptq_gemm(a: torch.Tensor, packed: PackedW4, c: torch.Tensor,
+              bias: Optional[torch.Tensor] = None) -> None:
+    """Mirror of marlin::gptq_gemm (marlin.h:17-25): C[M,N] = A[M,K] . dequant(W) (+ bias),
+    fp32 accumulate, written into the pre-allocated `c`.  AWQ and GPTQ share it, as in the
+    reference (has_zp true/false): zero points live in the prepacked scale/zero table."""
+    L = _lib.lib()
+    g = _gemm_args(a, packed, c, bias)
+    if g.M == 0:
+        return
+    need = L.slm_w4a16_gemm_workspace_bytes(C.byref(g))
+    if need:
+        ws = reserve_workspace(need, a.device)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
+    check(L.slm_w4a16_gemm(C.byref(g), _stream()), "slm_w4a16_gemm")
+
+
+def w4_dequant(packed: PackedW4) -> torch.Tensor:
+    """Dense [K, N] weights from the packed form (debug / parity; same dequant code as the GEMM)."""
+    L = _lib.lib()
+    w = torch.empty(packed.K, packed.N, dtype=packed.dtype, device=packed.wq.device)
+    check(L.slm_w4_dequant(packed.wq.data_ptr(), packed.sz.data_ptr(), packed.K, packed.N,
+                           packed.group_size, SLM_BF16 if packed.dtype == torch.bfloat16 else SLM_F16,
+                           w.data_ptr(), _stream()), "slm_w4_dequant")
+    return w
+
+
+# ---------------------------------------------------------------------------------------
+# glue ops (next rows f1/f2)
+# ---------------------------------------------------------------------------------------
+def rms_norm(out: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, eps: float,
+             residual: Optional[torch.Tensor] = None) -> None:
+    """kernel::rms_norm / rms_norm_residual (layernorm_kernels.cu:15,125)."""
+    L = _lib.lib()
+    _require_gpu(out, x, weight, residual)
+    if not (x.is_contiguous() and out.is_contiguous() and weight.is_contiguous()):
+        raise SlmError("rms_norm needs contiguous tensors")
+    if residual is not None and not residual.is_contiguous():
+        raise SlmError("rms_norm needs a contiguous residual")
+    dim = x.size(-1)
+    check(L.slm_rms_norm(out.data_ptr(), x.data_ptr(), weight.data_ptr(),
+                         residual.data_ptr() if residual is not None else None,
+                         x.numel() // dim, dim, float(eps), _dtype_code(x), _stream()),
+          "slm_rms_norm")
+
+
+def apply_rotary_pos_emb(query: torch.Tensor, key: torch.Tensor, positions: torch.Tensor,
+                         cos_sin: torch.Tensor, rotary_dim: int, interleaved: bool,
+                         value: Optional[torch.Tensor] = None,
+                         slot_ids: Optional[torch.Tensor] = None,
+                         key_cache: Optional[torch.Tensor] = None,
+                         value_cache: Optional[torch.Tensor] = None) -> None:
+    """kernel::apply_rotary_pos_emb (pos_embedding_kernels.cu:83-121), in place on query/key
+    [n_tokens, n_heads, head_dim]; with value/slot_ids/caches given it also performs the KV
+    append that follows it in AttentionImpl::forward (attention.cpp:36-42) in the same launch."""
+    L = _lib.lib()
+    _require_gpu(query, key, positions, cos_sin, value, slot_ids, key_cache, value_cache)
+    if query.stride(-1) != 1 or key.stride(-1) != 1 or query.stride(1) != query.size(2) or \
+            key.stride(1) != key.size(2):
+        raise SlmError("query/key must be contiguous in their last two dims")
+    if positions.dtype != torch.int32 or not cos_sin.is_contiguous():
+        raise SlmError("positions must be int32; cos_sin contiguous")
+    is_f32 = 1 if cos_sin.dtype == torch.float32 else 0
+    if not is_f32 and cos_sin.dtype != query.dtype:
+        raise SlmError("cos_sin must be fp32 or the activation dtype")
+    append = slot_ids is not None
+    if append and (value is None or key_cache is None or value_cache is None):
+        raise SlmError("append needs value, key_cache and value_cache")
+    check(L.slm_rope_kv_append(
+        query.data_ptr(), query.stride(0), key.data_ptr(), key.stride(0),
+        value.data_ptr() if append else None, value.stride(0) if append else 0,
+        positions.data_ptr(), cos_sin.data_ptr(), is_f32, int(rotary_dim),
+        1 if interleaved else 0, slot_ids.data_ptr() if append else None,
+        key_cache.data_ptr() if append else None, value_cache.data_ptr() if append else None,
+        query.size(0), query.size(1), key.size(1), query.size(2), _dtype_code(query), _stream()),
+        "slm_rope_kv_append")
+
+
+def silu_and_mul(out: torch.Tensor, x: torch.Tensor) -> None:
+    """kernel::act_and_mul with SiLU (activation_kernels.cu:84): out = silu(x[:, :d]) * x[:, d:]."""
+    L = _lib.lib()
+    _require_gpu(out, x)
+    if not (x.is_contiguous() and out.is_contiguous()):
+        raise SlmError("silu_and_mul needs contiguous tensors")
+    d = x.size(-1) // 2
+    check(L.slm_silu_mul(out.data_ptr(), x.data_ptr(), x.numel() // (2 * d), d, _dtype_code(x),
+                         _stream()), "slm_silu_mul")

@@ -86,3 +86,86 @@ def make_paged_case(seed, batch, max_q_len, max_kv_len, n_heads, n_kv_heads, hea
         kv_cu_lens=np.concatenate([[0], np.cumsum(kv_lens)]).astype(np.int32),
         block_table=table, block_cu_lens=bcu, block_size=block_size,
         max_q_len=max(q_lens), max_kv_len=max(kv_lens))
+
+
+# ------------------------------------------------------------------ int4 checkpoint formats
+# numpy packers for the two on-disk formats (test infrastructure).  Pinned to the reference's
+# python packers (tests/kernels/quant_utils.py:101-198) by tests/test_oracle.py::
+# test_numpy_packers_match_reference_format, which round-trips the committed golden tensors.
+AWQ_ORDER = np.array([0, 2, 4, 6, 1, 3, 5, 7])
+
+
+def pack_rows(q: np.ndarray) -> np.ndarray:
+    """[K, N] ints in 0..15 -> [K/8, N] int32, nibble (k % 8) at bit 4*(k%8) (GPTQ qweight)."""
+    q = q.astype(np.uint32)
+    out = np.zeros((q.shape[0] // 8, q.shape[1]), dtype=np.uint32)
+    for i in range(8):
+        out |= q[i::8, :] << (4 * i)
+    return out.view(np.int32)
+
+
+def pack_cols(q: np.ndarray) -> np.ndarray:
+    """[R, N] -> [R, N/8] int32, nibble (n % 8) at bit 4*(n%8) (GPTQ qzeros)."""
+    q = q.astype(np.uint32)
+    out = np.zeros((q.shape[0], q.shape[1] // 8), dtype=np.uint32)
+    for i in range(8):
+        out |= q[:, i::8] << (4 * i)
+    return out.view(np.int32)
+
+
+def pack_awq(q: np.ndarray) -> np.ndarray:
+    """[R, N] -> [R, N/8] int32 with the AWQ [0,2,4,6,1,3,5,7] interleave."""
+    r, n = q.shape
+    qi = q.reshape(-1, 8)[:, AWQ_ORDER].reshape(r, n)
+    return pack_cols(qi)
+
+
+def unpack_rows(p: np.ndarray) -> np.ndarray:
+    p = p.view(np.uint32)
+    out = np.zeros((p.shape[0] * 8, p.shape[1]), dtype=np.int32)
+    for i in range(8):
+        out[i::8, :] = (p >> (4 * i)) & 0xF
+    return out
+
+
+def unpack_cols(p: np.ndarray) -> np.ndarray:
+    p = p.view(np.uint32)
+    out = np.zeros((p.shape[0], p.shape[1] * 8), dtype=np.int32)
+    for i in range(8):
+        out[:, i::8] = (p >> (4 * i)) & 0xF
+    return out
+
+
+def unpack_awq(p: np.ndarray) -> np.ndarray:
+    u = unpack_cols(p)
+    inv = np.argsort(AWQ_ORDER)
+    return u.reshape(-1, 8)[:, inv].reshape(u.shape)
+
+
+def make_quant_case(seed, K, N, group_size, fmt, dtype_bits="bf16", act_order=False,
+                    sym_zero=False):
+    """Random int4 layer in checkpoint format.  Returns dict with packed tensors + integer truth.
+    scales are drawn in a realistic range and rounded to the 16-bit dtype."""
+    rng = np.random.default_rng(seed)
+    gs = K if group_size in (-1, 0) else group_size
+    G = K // gs
+    q = rng.integers(0, 16, size=(K, N)).astype(np.int32)
+    s = rng.uniform(0.005, 0.02, size=(G, N)).astype(np.float32)
+    if dtype_bits == "bf16":
+        s_bits = f32_to_bf16_bits(s)
+        s = bf16_bits_to_f32(s_bits)
+    else:
+        s_bits = s.astype(np.float16).view(np.uint16)
+        s = s_bits.view(np.float16).astype(np.float32)
+    if fmt == "awq":
+        z = rng.integers(0, 16, size=(G, N)).astype(np.int32)
+        d = dict(qweight=pack_awq(q), qzeros=pack_awq(z), z_eff=z)
+        g_idx = None
+    else:
+        z_stored = np.full((G, N), 7, np.int32) if sym_zero else rng.integers(0, 16, size=(G, N)).astype(np.int32)
+        g_idx = None
+        if act_order:
+            g_idx = (np.arange(K) // gs)[rng.permutation(K)].astype(np.int32)
+        d = dict(qweight=pack_rows(q), qzeros=pack_cols(z_stored), z_eff=z_stored + 1)
+    d.update(q=q, scales=s, scales_bits=s_bits, g_idx=g_idx, K=K, N=N, group_size=gs, fmt=fmt)
+    return d

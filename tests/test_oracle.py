@@ -122,3 +122,25 @@ def test_set_kv_cache_and_gemm():
     a = rng.standard_normal((5, 33), dtype=np.float32)
     w = rng.standard_normal((33, 17), dtype=np.float32)
     np.testing.assert_allclose(oracle.gemm_f32(a, w), a @ w, rtol=1e-5, atol=1e-5)
+
+
+def test_numpy_packers_match_reference_format():
+    """tests/helpers.py packers reproduce the golden tensors packed by the reference's own
+    quant_utils.py (pack_rows / pack_cols / pack_awq_weights)."""
+    for name, c in QUANT.items():
+        if name.startswith("gptq"):
+            assert np.array_equal(helpers.pack_rows(helpers.unpack_rows(c["qweight"])), c["qweight"])
+            assert np.array_equal(helpers.pack_cols(helpers.unpack_cols(c["qzeros"])), c["qzeros"])
+            gs = int(c["group_size"][0])
+            w = c["scales"].astype(np.float32)[c["g_idx"]] * (
+                helpers.unpack_rows(c["qweight"]) - (helpers.unpack_cols(c["qzeros"]) + 1)[c["g_idx"]])
+            np.testing.assert_array_equal(w.astype(np.float32), c["w"])
+            assert gs > 0
+        else:
+            q = helpers.unpack_awq(c["qweight"])
+            assert np.array_equal(helpers.pack_awq(q), c["qweight"])
+            z = helpers.unpack_awq(c["qzeros"])
+            gs = int(c["group_size"][0])
+            gi = np.arange(q.shape[0]) // gs
+            w = c["scales"].astype(np.float32)[gi] * (q - z[gi])
+            np.testing.assert_array_equal(w.astype(np.float32), c["w"])

@@ -1,0 +1,190 @@
+"""GPU parity tests for the int4 path through the C ABI: prepack (bit-exact), dequant
+(bit-exact vs round-to-nearest of the oracle's fp32 value) and the MFMA GEMM.
+
+Structure follows the reference's tests:
+  * tests/kernels/marlin_gemm_test.py:47-107  (M x N x K x group x act_order grid; metric
+    mean|C - C_ref| / mean|C_ref| < 1e-3 for fp16; we state 8e-3 for bf16 = one bf16 ulp class)
+  * tests/kernels/marlin_repack_test.py:16-84 (repack bit-exact) -- the Marlin byte layout is an
+    NVIDIA artefact, so bit-exactness is asserted on our layout through the dequant round trip
+  * src/layers/quantization/qlinear_impl_test.cpp:10-98 (GPTQ fixture; linear vs dequant+matmul)
+The reference never tested zero points (marlin_gemm_test.py:97 "TODO: test with zero point");
+we do (AWQ asymmetric, GPTQ arbitrary stored zeros).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _tdtype(bits):
+    return torch.bfloat16 if bits == "bf16" else torch.float16
+
+
+def _to_dev(case, bits):
+    dt = _tdtype(bits)
+    qweight = torch.from_numpy(case["qweight"]).to(DEV)
+    qzeros = torch.from_numpy(case["qzeros"]).to(DEV)
+    scales = torch.from_numpy(case["scales_bits"].view(np.int16)).to(DEV).view(dt)
+    g_idx = torch.from_numpy(case["g_idx"]).to(DEV) if case["g_idx"] is not None else None
+    return qweight, qzeros, scales, g_idx
+
+
+def _pack(case, bits):
+    from scalellm_amd import kernels
+    qweight, qzeros, scales, g_idx = _to_dev(case, bits)
+    if case["fmt"] == "awq":
+        return kernels.awq_repack(qweight, qzeros, scales, case["group_size"])
+    return kernels.gptq_repack(qweight, qzeros, scales, case["group_size"], g_idx)
+
+
+def _oracle_w(case):
+    sc = case["scales"]
+    if case["fmt"] == "awq":
+        return oracle.awq_dequant(case["qweight"], case["qzeros"], sc, case["group_size"])
+    return oracle.gptq_dequant(case["qweight"], case["qzeros"], sc, case["group_size"], case["g_idx"])
+
+
+def _round_bits(w_f32, bits):
+    if bits == "bf16":
+        return helpers.f32_to_bf16_bits(w_f32)
+    return w_f32.astype(np.float16).view(np.uint16)
+
+
+@pytest.mark.parametrize("bits", ["bf16", "f16"])
+@pytest.mark.parametrize("fmt,gs,act", [("gptq", 128, False), ("gptq", 32, False), ("gptq", -1, False),
+                                        ("gptq", 64, True), ("awq", 128, False), ("awq", 64, False),
+                                        ("awq", 32, False)])
+def test_prepack_dequant_roundtrip_bit_exact(bits, fmt, gs, act):
+    from scalellm_amd import kernels
+    case = helpers.make_quant_case(11, 256, 96, gs, fmt, bits, act_order=act)
+    packed = _pack(case, bits)
+    w = kernels.w4_dequant(packed)
+    torch.cuda.synchronize()
+    got = w.view(torch.int16).cpu().numpy().view(np.uint16)
+    ref = _oracle_w(case)  # fp32, exact (q - z) * s
+    if act:  # packed rows are sorted by group: row k' of the packed matrix = checkpoint row perm[k']
+        perm = packed.perm.cpu().numpy()
+        ref = ref[perm]
+    # (q - z) * s has <= 13 significant bits: the single rounding to T is the only error source
+    assert np.array_equal(got, _round_bits(ref, bits))
+
+
+def test_golden_gptq_small_fixture_on_gpu():
+    # the reference's own fixture (qlinear_impl_test.cpp:10-22) through prepack + dequant
+    from scalellm_amd import kernels
+    z = np.load(helpers.GOLDEN + "/gptq_small.npz")
+    qweight = torch.from_numpy(z["qweight"]).to(DEV)
+    qzeros = torch.from_numpy(z["qzeros"]).to(DEV)
+    scales = torch.from_numpy(z["scales"].view(np.int16)).to(DEV).view(torch.float16)
+    g_idx = torch.from_numpy(z["g_idx"]).to(DEV)
+    packed = kernels.gptq_repack(qweight, qzeros, scales, 128, g_idx)
+    w = kernels.w4_dequant(packed).float().cpu().numpy()
+    np.testing.assert_array_equal(w, z["w"].astype(np.float16).astype(np.float32))
+
+
+def _rel_err(c, ref):
+    return float(np.abs(c - ref).mean() / np.abs(ref).mean())
+
+
+GEMM_TOL = {"f16": 1e-3, "bf16": 8e-3}  # marlin_gemm_test.py:104-107; bf16 = 8x (8 fewer mantissa bits)
+
+
+def _run_gemm(case, bits, M, bias=False, seed=0):
+    from scalellm_amd import kernels
+    dt = _tdtype(bits)
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    a = torch.randn(M, case["K"], device=DEV, dtype=dt, generator=g)
+    b = torch.randn(case["N"], device=DEV, dtype=dt, generator=g) if bias else None
+    packed = _pack(case, bits)
+    c = torch.full((M, case["N"]), float("nan"), device=DEV, dtype=dt)
+    kernels.gptq_gemm(a, packed, c, b)
+    torch.cuda.synchronize()
+    ref = oracle.gemm_f32(a.float().cpu().numpy(), _oracle_w(case))
+    if bias:
+        ref = ref + b.float().cpu().numpy()[None, :]
+    out = c.float().cpu().numpy()
+    assert not np.isnan(out).any()
+    return out, ref
+
+
+@pytest.mark.parametrize("bits", ["f16", "bf16"])
+def test_reference_marlin_grid(bits):
+    # marlin_gemm_test.py:47-56 axes: m {16,32,64} n {64,128,256,512} k {128,256}
+    # group {-1,32,64,128} act_order {F,T}; + ragged m, zero points, both formats
+    i = 0
+    for M in (1, 16, 32, 33, 64, 100):
+        for N, K in ((64, 128), (128, 256), (256, 128), (512, 256)):
+            for gs in (-1, 32, 64, 128):
+                for fmt, act in (("gptq", False), ("gptq", True), ("awq", False)):
+                    i += 1
+                    if i % 3 != (M % 3):  # thin the full product (still ~100 cases per dtype)
+                        continue
+                    if act and (gs == -1 or gs == K):
+                        continue
+                    case = helpers.make_quant_case(100 + i, K, N, gs, fmt, bits, act_order=act)
+                    out, ref = _run_gemm(case, bits, M, bias=(i % 2 == 0), seed=i)
+                    err = _rel_err(out, ref)
+                    assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, err)
+
+
+@pytest.mark.parametrize("M", [1, 32, 256])
+@pytest.mark.parametrize("K,N", [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)])
+def test_llama3_8b_layer_shapes_awq(M, K, N):
+    """BASELINE config 3 shapes (AWQ, group 128, asymmetric zeros) at full size.  The fp32 oracle
+    GEMM at 4096x28672 is too slow for the suite, so the check is the size-independent identity
+    int4_gemm(A) == dense_gemm(A, dequant(W)) with dequant validated bit-exact above."""
+    from scalellm_amd import kernels
+    case = helpers.make_quant_case(K + N, K, N, 128, "awq", "bf16")
+    packed = _pack(case, "bf16")
+    g = torch.Generator(device=DEV).manual_seed(M)
+    a = torch.randn(M, K, device=DEV, dtype=torch.bfloat16, generator=g)
+    c = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    kernels.gptq_gemm(a, packed, c)
+    w = kernels.w4_dequant(packed)
+    ref = (a.float() @ w.float())
+    torch.cuda.synchronize()
+    err = float((c.float() - ref).abs().mean() / ref.abs().mean())
+    assert err < 4e-3, err  # only the output rounding to bf16 + fp32 summation order differ
+    # spot-check dequant against the oracle on a slab of columns
+    w_ref = oracle.awq_dequant(case["qweight"][:, :16], case["qzeros"][:, :16],
+                               case["scales"][:, :128], 128)
+    got = w[:, :128].view(torch.int16).cpu().numpy().view(np.uint16)
+    assert np.array_equal(got, helpers.f32_to_bf16_bits(w_ref))
+
+
+def test_gemm_linearity_and_strided_rows():
+    # size-independent property: GEMM is linear in A; also A / C row strides (lda, ldc > width)
+    from scalellm_amd import kernels
+    case = helpers.make_quant_case(5, 512, 256, 128, "gptq", "f16", sym_zero=True)
+    packed = _pack(case, "f16")
+    g = torch.Generator(device=DEV).manual_seed(1)
+    big = torch.randn(48, 512 + 64, device=DEV, dtype=torch.float16, generator=g)
+    a = big[:, :512]
+    cbuf = torch.zeros(48, 256 + 8, device=DEV, dtype=torch.float16)
+    c = cbuf[:, :256]
+    kernels.gptq_gemm(a, packed, c)
+    c2 = torch.empty(48, 256, device=DEV, dtype=torch.float16)
+    kernels.gptq_gemm((2 * a).contiguous(), packed, c2)
+    torch.cuda.synchronize()
+    assert float(cbuf[:, 256:].abs().sum()) == 0.0
+    ref = oracle.gemm_f32(a.float().cpu().numpy(), _oracle_w(case))
+    assert _rel_err(c.float().cpu().numpy(), ref) < 1e-3
+    np.testing.assert_allclose(c2.float().cpu().numpy(), 2 * c.float().cpu().numpy(), rtol=2e-3, atol=2e-3)
+
+
+def test_w4_rejects_bad_shapes():
+    from scalellm_amd import kernels
+    from scalellm_amd._lib import SlmError
+    case = helpers.make_quant_case(1, 128, 64, 128, "gptq", "f16")
+    packed = _pack(case, "f16")
+    a = torch.zeros(4, 64, device=DEV, dtype=torch.float16)  # wrong K
+    with pytest.raises(SlmError):
+        kernels.gptq_gemm(a, packed, torch.zeros(4, 64, device=DEV, dtype=torch.float16))
+    with pytest.raises(SlmError):  # dtype mismatch with the prepacked scales
+        kernels.gptq_gemm(torch.zeros(4, 128, device=DEV, dtype=torch.bfloat16), packed,
+                          torch.zeros(4, 64, device=DEV, dtype=torch.bfloat16))

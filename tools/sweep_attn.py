@@ -56,10 +56,14 @@ def main():
         nbytes = algo_bytes(bs, L, H, HKV, D, B)
         if bs >= 128:
             splits_opts = [1, 2, 4]
+        elif bs >= 64:
+            splits_opts = [1, 2, 4, 8]
         elif bs >= 16:
-            splits_opts = [4, 8, 16, 32]
+            splits_opts = [2, 4, 8, 16, 32]
+        elif bs >= 4:
+            splits_opts = [8, 16, 32, 64]
         else:
-            splits_opts = [32, 64, 128, 256]
+            splits_opts = [16, 32, 64, 128, 256]
         variants = []
         for u, nt, nw, hgw, sp in itertools.product([2, 4], [1, 0], [8, 4], [8, 1], splits_opts):
             if args.quick and (nt == 0 or nw == 4):
@@ -83,12 +87,23 @@ def main():
             else:
                 err = (out.float() - ref).abs().max().item()
                 assert err < 2e-2, (v, err)
+        # one hipGraph per variant holding `iters` back-to-back launches: replay time is pure GPU
+        # time (python/ctypes enqueue cost ~20 us per call would otherwise dominate small batches)
+        graphs = []
+        for i, v in enumerate(variants):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for _ in range(args.iters):
+                    run(v)
+            graphs.append(gr)
+        for gr in graphs:
+            gr.replay()
+        torch.cuda.synchronize()
         for _ in range(args.rounds):
             for i, v in enumerate(variants):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(args.iters):
-                    run(v)
+                graphs[i].replay()
                 e1.record()
                 torch.cuda.synchronize()
                 times[i].append(e0.elapsed_time(e1) / args.iters * 1e3)  # us
