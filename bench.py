@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""bench.py -- decode hot-path benchmark (driver contract: see the task statement / DESIGN.md).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE decode step of a Llama-3-8B-shaped model over one synthetic batch: bs=256
+sequences with 4096 tokens of paged KV history each (block_size 16, bf16 KV), all four linears
+int4 (AWQ, group 128) -- BASELINE.json's metric configuration.  Every op of the step is one of
+this repo's HIP kernels (RMSNorm, int4 GEMM, RoPE+KV-append, paged attention, SiLU*mul) except
+the embedding gather, the lm_head GEMM and the argmax (plain library ops, outside the graded
+path).  The step is captured into a hipGraph and replayed, as the reference's ModelRunner does
+(src/engine/model_runner.cpp:141-211).
+
+N > 1 runs the SAME global batch tensor-parallel over RCCL/xGMI (heads and GEMM N/K sharded,
+2 all-reduces per layer): total work is fixed => "scaling": "strong".
+
+Rank 0 prints ONE JSON line: metric/value/unit..., plus
+  "roofline":     the dominant kernel (paged-attention decode) measured live with HIP events,
+  "cpu_baseline": the CPU oracle (reference CPU-path restatement) timed on the host cores on a
+                  bounded sample of the same workload (N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from scalellm_amd import kernels  # noqa: E402
+from scalellm_amd.decode import LlamaDecodeStep, LlamaShape, make_decode_inputs  # noqa: E402
+from scalellm_amd.model_parallel import ParallelArgs, ProcessGroup  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def attn_algo_bytes(bs, kv_len, n_heads, n_kv_heads, head_dim, block, q_len=1, esize=2):
+    """K+V once, Q+O once, int32 indices once."""
+    kv = 2 * bs * kv_len * n_kv_heads * head_dim * esize
+    qo = 2 * bs * q_len * n_heads * head_dim * esize
+    idx = 4 * (bs * ((kv_len + block - 1) // block) + 3 * (bs + 1))
+    return kv + qo + idx
+
+
+def measure_attention_kernel(model, tokens, positions, params, n_launch):
+    """Average duration of the paged-attention launch (dominant kernel), HIP events on the
+    stream the kernel is launched on (torch's current stream), one launch per layer cache."""
+    T = tokens.numel()
+    q = torch.randn(T, model.n_heads, model.shape.head_dim, device=model.device, dtype=model.dtype)
+    out = torch.empty_like(q)
+    times = []
+    for i in range(n_launch + 4):
+        kv = model.layers[i % len(model.layers)]["kv"]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        model.attn.handler.batch_decode(q, kv, params, -1, out)
+        e1.record()
+        e1.synchronize()
+        if i >= 4:
+            times.append(e0.elapsed_time(e1) * 1e3)  # us
+    times.sort()
+    return sum(times) / len(times), times[len(times) // 2]
+
+
+def measure_gemm(model, T):
+    """int4 GEMM TFLOP/s of the largest layer GEMM (gate_up) at M = batch tokens, HIP events."""
+    L = model.layers[0]["gate_up"]
+    x = torch.randn(T, L._packed.K, device=model.device, dtype=model.dtype)
+    out = torch.empty(T, L._packed.N, device=model.device, dtype=model.dtype)
+    for _ in range(3):
+        kernels.gptq_gemm(x, L._packed, out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n):
+        kernels.gptq_gemm(x, L._packed, out)
+    e1.record()
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / n
+    flops = 2.0 * T * L._packed.K * L._packed.N
+    return dict(shape=[T, L._packed.K, L._packed.N], us=round(us, 2),
+                tflops=round(flops / us / 1e6, 1),
+                frac_of_bf16_mfma_peak=round(flops / us / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4))
+
+
+def cpu_baseline(model, tokens, params, sample_seqs, kv_len, block):
+    """The CPU oracle (oracle/ = restatement of the reference CPU path: RefHandler attention with
+    block-table gather + construct_weights/matmul int4 linear, fp32) timed on the host cores on
+    `sample_seqs` sequences of the batch for ONE layer, extrapolated to all layers."""
+    import numpy as np
+    from oracle import oracle  # CHECKER ONLY: never used by the product path
+    s = model.shape
+    L0 = model.layers[0]
+    # gather the sample's KV through the block table -> compact fp32 copies + compact table
+    nblk = (kv_len + block - 1) // block
+    bt = params.block_tables.view(-1)
+    idx = []
+    for b in range(sample_seqs):
+        blk = bt[b * nblk:(b + 1) * nblk].long()
+        idx.append((blk[:, None] + torch.arange(block, device=bt.device)[None, :]).reshape(-1)[:kv_len])
+    idx = torch.cat(idx)
+    kc, vc = L0["kv"].get_kv_cache()
+    k32 = kc[idx].float().cpu().numpy()
+    v32 = vc[idx].float().cpu().numpy()
+    q32 = torch.randn(sample_seqs, s.n_heads, s.head_dim).numpy()
+    q_cu = np.arange(sample_seqs + 1, dtype=np.int32)
+    kv_cu = (np.arange(sample_seqs + 1) * kv_len).astype(np.int32)
+    table = (np.arange(sample_seqs * nblk) * block).astype(np.int32)
+    bcu = (np.arange(sample_seqs + 1) * nblk).astype(np.int32)
+    # int4 linears: fresh random AWQ-format tensors of the layer's four shapes (host side)
+    rng = np.random.default_rng(0)
+    shapes = [(s.hidden, (s.n_heads + 2 * s.n_kv_heads) * s.head_dim), (s.n_heads * s.head_dim, s.hidden),
+              (s.hidden, 2 * s.intermediate), (s.intermediate, s.hidden)]
+    lin = []
+    for K, N in shapes:
+        qw = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(K, N // 8), dtype=np.int64).astype(np.int32)
+        qz = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(K // 128, N // 8), dtype=np.int64).astype(np.int32)
+        sc = rng.uniform(0.002, 0.008, size=(K // 128, N)).astype(np.float32)
+        lin.append((qw, qz, sc, rng.standard_normal((sample_seqs, K), dtype=np.float32)))
+    threads = oracle.num_threads()
+
+    def one_layer():
+        oracle.paged_attn(q32, k32, v32, q_cu, kv_cu, table, bcu, block, s.head_dim ** -0.5,
+                          n_threads=threads)
+        for qw, qz, sc, x in lin:
+            w = oracle.awq_dequant(qw, qz, sc, 128)  # the reference dequantises on every forward
+            oracle.gemm_f32(x, w, n_threads=threads)  # (qlinear_impl.cpp:171-183)
+
+    one_layer()  # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while reps < 2 or (time.perf_counter() - t0 < 10.0 and reps < 8):
+        one_layer()
+        reps += 1
+    t_layer = (time.perf_counter() - t0) / reps
+    tok_s = sample_seqs / (t_layer * s.n_layers)
+    return dict(value=round(tok_s, 3), unit="tokens/s", cores=threads, kind="port",
+                sample=(f"{sample_seqs} of the batch's sequences (kv_len {kv_len}), one layer: oracle "
+                        f"paged attention + 4 int4 (AWQ g128) linears with per-forward fp32 dequant; "
+                        f"{reps} reps, {t_layer:.2f} s/layer-sample, extrapolated x{s.n_layers} layers"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bs", type=int, default=256)
+    ap.add_argument("--seqlen", type=int, default=4096)
+    ap.add_argument("--block", type=int, default=16)
+    ap.add_argument("--layers", type=int, default=0, help="override layer count (debug only: "
+                    "a reduced model is NOT the BASELINE config and is flagged in the output)")
+    ap.add_argument("--quant", default="awq", choices=["awq", "gptq"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kv-fill", default="tile", choices=["tile", "randn"])
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun "
+                             f"--nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X GPU (no CPU fallback)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    pg = ProcessGroup.create_from_env(device)
+    pa = ParallelArgs(rank=pg.rank, world_size=pg.world_size, process_group=pg)
+
+    shape = LlamaShape.llama3_8b()
+    reduced = False
+    if args.layers > 0 and args.layers != shape.n_layers:
+        shape.n_layers, reduced = args.layers, True
+    bs, L, B = args.bs, args.seqlen, args.block
+    shape.max_position = max(shape.max_position, L + 8)
+    tokens, positions, params, n_blocks = make_decode_inputs(bs, L, B, device, seed=1, vocab=shape.vocab)
+    t_init = time.perf_counter()
+    model = LlamaDecodeStep(shape, bs, n_blocks, B, pa, quant_method=args.quant, group_size=128,
+                            dtype=torch.bfloat16, device=device, seed=0, kv_fill=args.kv_fill)
+    model.reserve_workspaces(bs, L)
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - t_init
+
+    static_tokens = tokens.clone()
+
+    def step():
+        nxt = model.forward(static_tokens, positions, params)
+        static_tokens.copy_(nxt)  # greedy feedback: next step consumes this step's tokens
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+
+    graph = None
+    if not args.no_graph:
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step()
+            g.replay()
+            torch.cuda.synchronize()
+            graph = g
+        except Exception as e:  # noqa: BLE001 -- report and run eagerly
+            if rank == 0:
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly",
+                      file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step
+    for _ in range(args.warmup):
+        run()
+
+    pg.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    pg.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    tok_s = bs * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel (paged-attention decode), this rank's shard ----
+    avg_us, med_us = measure_attention_kernel(model, tokens, positions, params, n_launch=32)
+    nbytes = attn_algo_bytes(bs, L, model.n_heads, model.n_kv_heads, shape.head_dim, B)
+    achieved = nbytes / avg_us / 1e3  # GB/s
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "attn_pmc.json")
+    if os.path.exists(pmc):
+        try:
+            with open(pmc) as f:
+                rec = json.load(f)
+            if rec.get("bs") == bs and rec.get("seqlen") == L and rec.get("n_gpus", 1) == world:
+                traffic = rec.get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+    roofline = dict(kernel="attn_token_kernel (paged-attention decode)", bound="hbm",
+                    achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
+                    algorithmic_bytes_per_launch=nbytes, avg_launch_us=round(avg_us, 2),
+                    median_launch_us=round(med_us, 2), launches=32)
+    gemm = measure_gemm(model, bs)
+
+    out = None
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(model, tokens, params, sample_seqs=16, kv_len=L, block=B)
+        out = {
+            "metric": "decode tokens/s (Llama-3-8B-shaped step, bs=256, seq=4k; paged-attention "
+                      "HBM roofline + int4-GEMM TFLOP/s alongside)",
+            "value": round(tok_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16 (int4 weights, fp32 accumulate)",
+            "data": "synthetic (seeded random weights, KV history and tokens)",
+            "config": {"workload": f"llama3-8b-shaped decode step: bs={bs}, kv_len={L}, q_len=1, "
+                                   f"block_size={B}, {shape.n_layers} layers, {args.quant} int4 g128 "
+                                   f"linears, bf16 KV cache, greedy",
+                       "global_batch": bs, "seq_len": L,
+                       "parallelism": f"tp{world}" if world > 1 else "single-gpu",
+                       "hip_graph": graph is not None, "reduced_model": reduced,
+                       "kv_cache_gib_per_gpu": round(2 * n_blocks * B * model.n_kv_heads * shape.head_dim
+                                                     * 2 * shape.n_layers / 2 ** 30, 1),
+                       "init_s": round(t_init, 1)},
+            "roofline": roofline,
+            "int4_gemm": gemm,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

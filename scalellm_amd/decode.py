@@ -1,0 +1,206 @@
+"""A Llama-shaped decode step assembled from the hot-path layers (scalellm_amd.layers), used by
+bench.py, __graft_entry__.smoke() and the layer-level tests.  It is NOT a model zoo: it exists to
+drive the hot path the way the reference's LlamaModelImpl::forward does (src/models/meta/llama.h
+:123-265): per layer RMSNorm -> qkv -> RoPE+append -> paged attention -> o_proj (row-parallel,
+all-reduce) -> RMSNorm -> gate_up -> SiLU*mul -> down (row-parallel, all-reduce); then final norm,
+lm_head (column-parallel, gathered) and greedy argmax.  All four linears are int4 (AWQ or GPTQ)
+-- the reference snapshot leaves fused qkv / gate_up un-quantised; here the whole
+layer is int4.  Weights are synthetic (seeded); there is no checkpoint IO on this path.
+
+One process per GPU; TP shards heads (attention needs no collective) and the GEMMs' N / K.
+The step is hipGraph-capturable: static buffers, no host sync, no allocation after warm-up.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from . import kernels
+from .layers import (Attention, ColumnParallelQLinear, HipAttnHandler, InputParameters, KVCache,
+                     QuantArgs, RowParallelQLinear)
+from .model_parallel import ParallelArgs
+
+
+@dataclass
+class LlamaShape:
+    hidden: int = 4096
+    n_heads: int = 32
+    n_kv_heads: int = 8
+    head_dim: int = 128
+    intermediate: int = 14336
+    n_layers: int = 32
+    vocab: int = 128256
+    rope_theta: float = 500000.0
+    rms_eps: float = 1e-5
+    max_position: int = 8192
+
+    @staticmethod
+    def llama3_8b() -> "LlamaShape":
+        return LlamaShape()
+
+    @staticmethod
+    def llama3_70b() -> "LlamaShape":  # in-tree defaults models/meta/llama.h:348-362
+        return LlamaShape(hidden=8192, n_heads=64, n_kv_heads=8, intermediate=28672, n_layers=80)
+
+    @staticmethod
+    def tiny() -> "LlamaShape":
+        return LlamaShape(hidden=256, n_heads=8, n_kv_heads=2, head_dim=32, intermediate=512,
+                          n_layers=2, vocab=1024, max_position=512)
+
+
+def _rand_int4_linear(gen, K, N, group_size, fmt, dtype, device):
+    """Random layer in CHECKPOINT format (AWQ [K,N/8] / GPTQ [K/8,N]); random bits = uniform nibbles."""
+    G = K // group_size
+    if fmt == "awq":
+        qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, (K, N // 8), device=device, generator=gen,
+                                dtype=torch.int64).to(torch.int32)
+    else:
+        qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 8, N), device=device, generator=gen,
+                                dtype=torch.int64).to(torch.int32)
+    qzeros = torch.randint(-2 ** 31, 2 ** 31 - 1, (G, N // 8), device=device, generator=gen,
+                           dtype=torch.int64).to(torch.int32)
+    scales = (torch.rand(G, N, device=device, generator=gen) * 0.006 + 0.002).to(dtype)
+    return {"qweight": qweight, "qzeros": qzeros, "scales": scales}
+
+
+class LlamaDecodeStep:
+    def __init__(self, shape: LlamaShape, max_batch_tokens: int, n_blocks: int, block_size: int,
+                 parallel_args: Optional[ParallelArgs] = None, quant_method: str = "awq",
+                 group_size: int = 128, dtype=torch.bfloat16, device="cuda", seed: int = 0,
+                 kv_fill: str = "none"):
+        pa = parallel_args or ParallelArgs()
+        self.shape, self.pa, self.dtype, self.device = shape, pa, dtype, torch.device(device)
+        tp = pa.world_size
+        assert shape.n_heads % tp == 0 and shape.intermediate % tp == 0 and shape.hidden % tp == 0
+        self.n_heads = shape.n_heads // tp
+        # KV heads are replicated when n_kv_heads < TP (qkv_parallel_linear.cpp:28-38)
+        self.n_kv_heads = max(shape.n_kv_heads // tp, 1)
+        self.block_size = block_size
+        D, H = shape.head_dim, shape.hidden
+        gen = torch.Generator(device=self.device).manual_seed(seed * 1000 + pa.rank)
+        qa = QuantArgs(quant_method=quant_method, bits=4, group_size=group_size,
+                       zero_point=(quant_method == "awq"))
+        inv_freq = 1.0 / (shape.rope_theta ** (torch.arange(0, D, 2, dtype=torch.float32,
+                                                              device=self.device) / D))
+        cos_sin = HipAttnHandler.build_cos_sin(D, shape.max_position, inv_freq)
+        handler = HipAttnHandler(sm_scale=D ** -0.5, rotary_dim=D, cos_sin=cos_sin, interleaved=False)
+        self.attn = Attention(self.n_heads, self.n_kv_heads, D, handler)
+        qkv_n = (self.n_heads + 2 * self.n_kv_heads) * D
+        self.layers = []
+        for _ in range(shape.n_layers):
+            L = {}
+            L["qkv"] = ColumnParallelQLinear(H, qkv_n * tp, False, qa, False, pa, dtype, self.device)
+            L["o"] = RowParallelQLinear(self.n_heads * D * tp, H, False, qa, True, pa, dtype, self.device)
+            L["gate_up"] = ColumnParallelQLinear(H, 2 * shape.intermediate, False, qa, False, pa, dtype,
+                                                 self.device)
+            L["down"] = RowParallelQLinear(shape.intermediate, H, False, qa, True, pa, dtype, self.device)
+            for name, (K, N) in {"qkv": (H, qkv_n), "o": (self.n_heads * D, H),
+                                 "gate_up": (H, 2 * shape.intermediate // tp),
+                                 "down": (shape.intermediate // tp, H)}.items():
+                L[name].load_state_dict(_rand_int4_linear(gen, K, N, group_size, quant_method, dtype,
+                                                          self.device))
+                L[name].verify_loaded_weights()
+                L[name]._repack()
+            L["in_norm"] = (1 + 0.05 * torch.randn(H, device=self.device, generator=gen)).to(dtype)
+            L["post_norm"] = (1 + 0.05 * torch.randn(H, device=self.device, generator=gen)).to(dtype)
+            L["kv"] = KVCache(n_blocks, block_size, self.n_kv_heads, D, dtype, self.device)
+            self.layers.append(L)
+        self.final_norm = (1 + 0.05 * torch.randn(H, device=self.device, generator=gen)).to(dtype)
+        # hidden-sharded embedding + all-gather (embedding.h:74-81); vocab-sharded lm_head, gathered
+        self.embed = (torch.randn(shape.vocab, H // tp, device=self.device, generator=gen) * 0.02).to(dtype)
+        self.lm_head = (torch.randn(H, shape.vocab // tp, device=self.device, generator=gen) * 0.02).to(dtype)
+        T = max_batch_tokens
+        e = lambda *s: torch.empty(*s, dtype=dtype, device=self.device)  # noqa: E731
+        self.buf = dict(resid=e(T, H), normed=e(T, H), qkv=e(T, qkv_n), attn=e(T, self.n_heads, D),
+                        o=e(T, H), gate_up=e(T, 2 * shape.intermediate // tp),
+                        act=e(T, shape.intermediate // tp), down=e(T, H))
+        if kv_fill != "none":
+            self.fill_kv(kv_fill, gen)
+
+    def fill_kv(self, mode: str, gen) -> None:
+        """Synthetic KV history.  'randn': every layer its own normal draw (slow for 100+ GiB);
+        'tile': one 256 MiB normal block tiled over every layer's cache (fast; random enough for
+        timing -- no two layers alias, nothing fits a cache)."""
+        blk = None
+        for L in self.layers:
+            for t in L["kv"].get_kv_cache():
+                if mode == "randn":
+                    t.normal_(generator=gen)
+                else:
+                    flat = t.view(-1)
+                    if blk is None:
+                        n = min(flat.numel(), 128 * 1024 * 1024)
+                        blk = torch.randn(n, device=self.device, dtype=self.dtype, generator=gen)
+                    reps = (flat.numel() + blk.numel() - 1) // blk.numel()
+                    for r in range(reps):
+                        seg = flat[r * blk.numel():(r + 1) * blk.numel()]
+                        seg.copy_(blk[:seg.numel()])
+
+    def reserve_workspaces(self, n_tokens: int, max_kv_len: int) -> None:
+        """Grow the kernel workspace once, before graph capture."""
+        s = self.shape
+        need = n_tokens * self.n_heads * 256 * (s.head_dim + 2) * 4  # worst-case split-KV partials
+        need = max(need, 64 * n_tokens * max(2 * s.intermediate // self.pa.world_size, s.hidden) * 4)
+        kernels.reserve_workspace(min(need, 4 << 30), self.device)
+
+    def forward(self, tokens: torch.Tensor, positions: torch.Tensor,
+                params: InputParameters) -> torch.Tensor:
+        """tokens/positions [T] int32 -> next-token ids [n_seqs] (greedy), last token per sequence."""
+        s, b, pa = self.shape, self.buf, self.pa
+        T = tokens.numel()
+        D = s.head_dim
+        resid, normed = b["resid"][:T], b["normed"][:T]
+        x = self.embed[tokens.long()]
+        if pa.world_size > 1:
+            from .model_parallel import gather_from_model_parallel_region
+            x = gather_from_model_parallel_region(x, pa)
+        resid.copy_(x)
+        delta = None
+        for L in self.layers:
+            # input RMSNorm (+ residual add of the previous block's output)
+            if delta is None:
+                kernels.rms_norm(normed, resid, L["in_norm"], s.rms_eps)
+            else:
+                kernels.rms_norm(normed, delta, L["in_norm"], s.rms_eps, residual=resid)
+            qkv = L["qkv"].forward(normed, out=b["qkv"][:T])
+            nq, nkv = self.n_heads * D, self.n_kv_heads * D
+            q, k, v = qkv[:, :nq], qkv[:, nq:nq + nkv], qkv[:, nq + nkv:]
+            attn = self.attn.forward(q, k, v, positions, L["kv"], params, output=b["attn"][:T])
+            delta = L["o"].forward(attn, out=b["o"][:T])
+            kernels.rms_norm(normed, delta, L["post_norm"], s.rms_eps, residual=resid)
+            gu = L["gate_up"].forward(normed, out=b["gate_up"][:T])
+            kernels.silu_and_mul(b["act"][:T], gu)
+            delta = L["down"].forward(b["act"][:T], out=b["down"][:T])
+        kernels.rms_norm(normed, delta, self.final_norm, s.rms_eps, residual=resid)
+        last = (params.q_cu_seq_lens[1:] - 1).long()
+        logits = normed[last] @ self.lm_head  # plain library GEMM (hipBLASLt): not on the graded path
+        if pa.world_size > 1:
+            from .model_parallel import gather_from_model_parallel_region
+            logits = gather_from_model_parallel_region(logits, pa)
+        return torch.argmax(logits.float(), dim=-1).to(torch.int32)
+
+
+def make_decode_inputs(batch: int, kv_len: int, block_size: int, device, seed: int = 0,
+                       q_len: int = 1, vocab: int = 128256):
+    """Synthetic decode batch in the engine's input format (engine/batch.cpp:77-270): every
+    sequence has kv_len tokens of history INCLUDING the q_len new ones; blocks are a seeded
+    random permutation (unique ids), block table = first-slot ids."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    nblk_seq = (kv_len + block_size - 1) // block_size
+    n_blocks = batch * nblk_seq + 2
+    perm = torch.randperm(n_blocks - 1, device=device, generator=g)[:batch * nblk_seq] + 1
+    table = (perm * block_size).to(torch.int32)
+    cu_blk = torch.arange(0, batch + 1, device=device, dtype=torch.int32) * nblk_seq
+    q_cu = torch.arange(0, batch + 1, device=device, dtype=torch.int32) * q_len
+    kv_cu = torch.arange(0, batch + 1, device=device, dtype=torch.int32) * kv_len
+    pos_in_seq = torch.arange(kv_len - q_len, kv_len, device=device)
+    positions = pos_in_seq.repeat(batch).to(torch.int32)
+    blk_of = (pos_in_seq // block_size)[None, :] + (torch.arange(batch, device=device) * nblk_seq)[:, None]
+    slots = (table[blk_of.reshape(-1).long()].long() + (pos_in_seq % block_size).repeat(batch)).to(torch.int32)
+    tokens = torch.randint(0, vocab, (batch * q_len,), device=device, generator=g).to(torch.int32)
+    params = InputParameters(q_cu_seq_lens=q_cu, kv_cu_seq_lens=kv_cu, new_cache_slots=slots,
+                             block_tables=table, cu_block_lens=cu_blk, q_max_seq_len=q_len,
+                             kv_max_seq_len=kv_len)
+    return tokens, positions, params, n_blocks

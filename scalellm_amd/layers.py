@@ -1,0 +1,232 @@
+"""Host-side mirror of the reference's LAYER-level operator API for the hot path, built on
+scalellm_amd.kernels (-> libslm_hip.so).  Same class / method names and argument meaning as
+the reference so parity tests read like the reference's own layer tests.
+
+  InputParameters      <- llm::InputParameters        src/models/parameters.h:11-56
+  KVCache              <- llm::KVCache                src/memory/kv_cache.h:11-67
+  HipAttnHandler       <- llm::ScaleAttnHandler       src/layers/attention/scale_attn_handler.cpp
+                          (AttentionHandler interface src/layers/attention/handler.h:15-48)
+  Attention            <- llm::AttentionImpl          src/layers/attention/attention.cpp:7-46
+  ColumnParallelQLinear / RowParallelQLinear
+                       <- {Column,Row}ParallelQLinear{AWQ,GPTQ}MarlinImpl
+                          src/layers/quantization/qlinear_awq_marlin_impl.cpp:128-366,
+                          qlinear_gptq_marlin_impl.cpp:74-330 (TP sharding dims, lazy repack on
+                          first forward, all-reduce then bias for row-parallel)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import kernels
+from .model_parallel import (ParallelArgs, gather_from_model_parallel_region,
+                             reduce_from_model_parallel_region)
+
+
+@dataclass
+class InputParameters:
+    """models/parameters.h:11-56 (the attention-relevant fields)."""
+    q_cu_seq_lens: torch.Tensor       # [batch + 1] int32
+    kv_cu_seq_lens: torch.Tensor      # [batch + 1] int32
+    new_cache_slots: torch.Tensor     # [n_tokens] int32
+    block_tables: torch.Tensor        # flattened first-slot ids
+    cu_block_lens: torch.Tensor       # [batch + 1] int32
+    q_max_seq_len: int = 0
+    kv_max_seq_len: int = 0
+
+
+class KVCache:
+    """[n_blocks * block_size, n_kv_heads, head_dim] K and V tensors (memory/kv_cache.cpp:15-27)."""
+
+    def __init__(self, n_blocks: int, block_size: int, n_kv_heads: int, head_dim: int,
+                 dtype: torch.dtype, device):
+        self._block_size = block_size
+        self.key_cache = torch.empty(n_blocks * block_size, n_kv_heads, head_dim, dtype=dtype,
+                                     device=device)
+        self.value_cache = torch.empty_like(self.key_cache)
+
+    def block_size(self) -> int:
+        return self._block_size
+
+    def get_kv_cache(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self.key_cache, self.value_cache
+
+    def set_kv_cache(self, slot_ids: torch.Tensor, keys: torch.Tensor, values: torch.Tensor) -> None:
+        kernels.set_kv_cache(slot_ids, keys, values, self.key_cache, self.value_cache)
+
+
+class HipAttnHandler:
+    """AttentionHandler over the HIP kernels (handler.h:15-48).  RoPE and the KV append are one
+    fused launch: apply_pos_emb() only records its inputs and append_kv_cache() issues the fused
+    kernel (the reference always calls them back to back: attention.cpp:36-39)."""
+
+    def __init__(self, sm_scale: float, logits_soft_cap: float = 0.0,
+                 alibi_slopes: Optional[torch.Tensor] = None, rotary_dim: int = 0,
+                 cos_sin: Optional[torch.Tensor] = None, interleaved: bool = False):
+        self.sm_scale = sm_scale
+        self.logits_soft_cap = logits_soft_cap
+        self.alibi_slopes = alibi_slopes
+        self.rotary_dim, self.cos_sin, self.interleaved = rotary_dim, cos_sin, interleaved
+        self._pending = None
+
+    @staticmethod
+    def build_cos_sin(rotary_dim: int, max_position: int, inv_freq: torch.Tensor) -> torch.Tensor:
+        """[max_position, rotary_dim] = cos | sin, fp32 (RotaryEmbeddingKernel pos_embedding.cpp
+        :183-197 builds the same table in the activation dtype; fp32 keeps RoPE exact)."""
+        t = torch.arange(max_position, dtype=torch.float32, device=inv_freq.device)
+        freqs = torch.einsum("i,j->ij", t, inv_freq.float())
+        return torch.cat([freqs.cos(), freqs.sin()], dim=-1).contiguous()
+
+    def apply_pos_emb(self, query, key, positions):
+        if self.cos_sin is not None and positions is not None:
+            self._pending = positions
+        return query, key
+
+    def append_kv_cache(self, kv_cache: KVCache, query, key, value, input_params: InputParameters):
+        kc, vc = kv_cache.get_kv_cache()
+        if self._pending is not None:
+            kernels.apply_rotary_pos_emb(query, key, self._pending, self.cos_sin, self.rotary_dim,
+                                         self.interleaved, value=value,
+                                         slot_ids=input_params.new_cache_slots, key_cache=kc,
+                                         value_cache=vc)
+            self._pending = None
+        else:
+            kernels.set_kv_cache(input_params.new_cache_slots, key, value, kc, vc)
+
+    def batch_decode(self, query, kv_cache: KVCache, input_params: InputParameters,
+                     sliding_window: int, output: torch.Tensor) -> None:
+        kc, vc = kv_cache.get_kv_cache()
+        kernels.paged_kv_varlen_mha(output, query, kc, vc, input_params.q_cu_seq_lens,
+                                    input_params.kv_cu_seq_lens, input_params.block_tables,
+                                    input_params.cu_block_lens, self.alibi_slopes,
+                                    kv_cache.block_size(), input_params.q_max_seq_len,
+                                    input_params.kv_max_seq_len, self.sm_scale,
+                                    self.logits_soft_cap, sliding_window)
+
+
+class Attention:
+    """AttentionImpl::forward (attention.cpp:22-46): rope -> append -> paged attention."""
+
+    def __init__(self, n_heads: int, n_kv_heads: int, head_dim: int, handler: HipAttnHandler,
+                 sliding_window: int = -1):
+        self.n_heads, self.n_kv_heads, self.head_dim = n_heads, n_kv_heads, head_dim
+        self.handler, self.sliding_window = handler, sliding_window
+
+    def forward(self, query, key, value, positions, kv_cache: KVCache,
+                input_params: InputParameters, output: Optional[torch.Tensor] = None):
+        T = query.size(0)
+        q = query.view(T, self.n_heads, self.head_dim)
+        k = key.view(T, self.n_kv_heads, self.head_dim)
+        v = value.view(T, self.n_kv_heads, self.head_dim)
+        q, k = self.handler.apply_pos_emb(q, k, positions)
+        self.handler.append_kv_cache(kv_cache, q, k, v, input_params)
+        if output is None:
+            output = torch.empty(T, self.n_heads, self.head_dim, dtype=query.dtype, device=query.device)
+        self.handler.batch_decode(q, kv_cache, input_params, self.sliding_window, output)
+        return output.view(T, self.n_heads * self.head_dim)
+
+
+# ---------------------------------------------------------------------------------------
+# int4 linear layers
+# ---------------------------------------------------------------------------------------
+@dataclass
+class QuantArgs:
+    """layers/quantization/quant_args.h:10-33."""
+    quant_method: str = "awq"   # "awq" | "gptq"
+    bits: int = 4
+    group_size: int = 128
+    desc_act: bool = False
+    zero_point: bool = True
+
+
+class _QLinearBase:
+    def __init__(self, in_features: int, out_features: int, bias: bool, quant_args: QuantArgs,
+                 parallel_args: ParallelArgs, dtype: torch.dtype, device):
+        if quant_args.bits != 4:
+            raise kernels.SlmError("only 4-bit weights are supported (int8 Marlin path: out of scope)")
+        self.in_features, self.out_features = in_features, out_features
+        self.quant_args, self.parallel_args = quant_args, parallel_args
+        self.dtype, self.device = dtype, device
+        self.has_bias = bias
+        self.bias: Optional[torch.Tensor] = None
+        self._ckpt: Dict[str, torch.Tensor] = {}
+        self._packed: Optional[kernels.PackedW4] = None
+
+    # checkpoint-format tensors for THIS rank's shard
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        for name in ("qweight", "qzeros", "scales", "g_idx", "bias"):
+            if name in sd:
+                self._ckpt[name] = sd[name].to(self.device)
+        self._packed = None
+
+    def verify_loaded_weights(self) -> None:
+        for name in ("qweight", "qzeros", "scales"):
+            assert name in self._ckpt, f"{name} is not loaded"
+        assert (not self.has_bias) or "bias" in self._ckpt, "bias is not loaded"
+
+    def _repack(self) -> None:  # lazily on first forward, like the reference (inside warm-up)
+        c = self._ckpt
+        scales = c["scales"].to(self.dtype).contiguous()
+        if self.quant_args.quant_method == "awq":
+            self._packed = kernels.awq_repack(c["qweight"], c["qzeros"], scales,
+                                              self.quant_args.group_size)
+        else:
+            self._packed = kernels.gptq_repack(c["qweight"], c["qzeros"], scales,
+                                               self.quant_args.group_size, c.get("g_idx"))
+        if self.has_bias:
+            self.bias = c["bias"].to(self.dtype).contiguous()
+        self._ckpt = {}
+
+    def _gemm(self, x: torch.Tensor, bias: Optional[torch.Tensor],
+              out: Optional[torch.Tensor]) -> torch.Tensor:
+        if self._packed is None:
+            self._repack()
+        x2 = x.reshape(-1, x.size(-1))
+        if out is None:
+            out = torch.empty(x2.size(0), self._packed.N, dtype=x.dtype, device=x.device)
+        kernels.gptq_gemm(x2, self._packed, out, bias)
+        return out
+
+
+class ColumnParallelQLinear(_QLinearBase):
+    """Y = X W + b with W sharded along N (qlinear_awq_marlin_impl.cpp:128-254).
+    in_features / out_features are the FULL sizes; this rank holds out_features / world_size."""
+
+    def __init__(self, in_features, out_features, bias, quant_args, gather_output,
+                 parallel_args, dtype, device):
+        super().__init__(in_features, out_features, bias, quant_args, parallel_args, dtype, device)
+        self.gather_output = gather_output
+
+    def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self._packed is None:
+            self._repack()
+        y = self._gemm(x, self.bias if self.has_bias else None, out)
+        if self.parallel_args.world_size > 1 and self.gather_output:
+            y = gather_from_model_parallel_region(y, self.parallel_args)
+        return y
+
+
+class RowParallelQLinear(_QLinearBase):
+    """Y = sum_ranks X_r W_r + b with W sharded along K (qlinear_awq_marlin_impl.cpp:257-366):
+    GEMM, all-reduce, THEN bias (:357-363)."""
+
+    def __init__(self, in_features, out_features, bias, quant_args, input_is_parallelized,
+                 parallel_args, dtype, device):
+        super().__init__(in_features, out_features, bias, quant_args, parallel_args, dtype, device)
+        self.input_is_parallelized = input_is_parallelized
+
+    def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self._packed is None:
+            self._repack()
+        if not self.input_is_parallelized and self.parallel_args.world_size > 1:
+            from .model_parallel import scatter_to_model_parallel_region
+            x = scatter_to_model_parallel_region(x, self.parallel_args).contiguous()
+        if self.parallel_args.world_size > 1:
+            y = self._gemm(x, None, out)
+            reduce_from_model_parallel_region(y, self.parallel_args)
+            if self.has_bias:
+                y.add_(self.bias)
+            return y
+        return self._gemm(x, self.bias if self.has_bias else None, out)
