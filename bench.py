@@ -160,7 +160,7 @@ def main():
     ap.add_argument("--quant", default="awq", choices=["awq", "gptq"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kv-fill", default="tile", choices=["tile", "randn"])
+    ap.add_argument("--kv-fill", default="randn", choices=["tile", "randn"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -606,6 +606,7 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
     kp.o_part = reinterpret_cast<float*>(a->workspace);
     kp.ml_part = kp.o_part + (size_t)a->n_tokens * a->n_heads * pl.n_splits * a->head_dim;
   }
+  hip_clear_error();
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t grid = (int64_t)a->n_tokens * pl.nhgb * pl.n_chunks * pl.n_splits;
   if (grid <= 0 || grid > 0x7fffffffLL) return SLM_ERR_INVALID_ARG;

@@ -102,6 +102,10 @@ __device__ __forceinline__ float group_sum(float v) {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// hipGetLastError() is per-thread sticky state shared with every other HIP user in the process
+// (torch, RCCL): clear stale errors when an entry point starts, so that hip_check_launch()
+// reports only OUR launch.
+inline void hip_clear_error() { (void)hipGetLastError(); }
 inline int hip_check_launch() { return hipGetLastError() == hipSuccess ? SLM_OK : SLM_ERR_LAUNCH; }
 
 inline bool is_pow2(int64_t x) { return x > 0 && (x & (x - 1)) == 0; }

@@ -192,6 +192,7 @@ SLM_API int slm_rms_norm(void* out, const void* x, const void* weight, void* res
   if (!aligned16(out) || !aligned16(x) || !aligned16(weight) || (residual && !aligned16(residual)))
     return SLM_ERR_ALIGNMENT;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hip_clear_error();
   const dim3 grid((unsigned)n_tokens), blk(256);
   if (dtype == SLM_BF16)
     hipLaunchKernelGGL(rms_norm_kernel<bf16_tag>, grid, blk, 0, st, (uint16_t*)out,
@@ -217,6 +218,7 @@ SLM_API int slm_rope_kv_append(void* q, int64_t q_token_stride, void* k, int64_t
   if (slot_ids && (!v || !key_cache || !value_cache)) return SLM_ERR_INVALID_ARG;
   if (dtype != SLM_F16 && dtype != SLM_BF16) return SLM_ERR_UNSUPPORTED;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hip_clear_error();
   const dim3 grid((unsigned)n_tokens), blk(256);
 #define SLM_ROPE(TT, CST)                                                                       \
   hipLaunchKernelGGL((rope_kv_append_kernel<TT, CST>), grid, blk, 0, st, (uint16_t*)q,           \
@@ -240,6 +242,7 @@ SLM_API int slm_silu_mul(void* out, const void* x, int64_t n_tokens, int64_t d, 
   if (d <= 0 || d % 8) return SLM_ERR_UNSUPPORTED;
   if (!aligned16(out) || !aligned16(x)) return SLM_ERR_ALIGNMENT;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hip_clear_error();
   const int64_t total = n_tokens * (d / 8);
   int64_t blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;

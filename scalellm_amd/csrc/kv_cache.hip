@@ -60,6 +60,7 @@ extern "C" SLM_API int slm_set_kv_cache(const int32_t* slot_ids, const void* key
   const bool vec16 = (row_bytes % 16 == 0) && (ksb % 16 == 0) && (vsb % 16 == 0) &&
                      aligned16(keys) && aligned16(values) && aligned16(key_cache) &&
                      aligned16(value_cache);
+  hip_clear_error();
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int vec = vec16 ? 16 : 2;
   int lanes = (row_bytes + vec - 1) / vec;

@@ -465,6 +465,7 @@ SLM_API int slm_w4_prepack(int32_t format, const int32_t* qweight, const int32_t
   if (K <= 0 || N <= 0 || K % 64 || N % 32 || group_size <= 0 || K % group_size)
     return SLM_ERR_UNSUPPORTED;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hip_clear_error();
   const int64_t words = K * N / 8;
   hipLaunchKernelGGL(w4_prepack_weight_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0,
                      st, format, reinterpret_cast<const uint32_t*>(qweight), perm, K, N,
@@ -485,6 +486,7 @@ SLM_API int slm_w4_dequant(const void* wq, const void* sz, int64_t K, int64_t N,
   if (K <= 0 || N <= 0 || K % 64 || N % 32 || group_size < 16 || K % group_size)
     return SLM_ERR_UNSUPPORTED;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hip_clear_error();
   const int64_t words = K * N / 8;
   const dim3 grid((unsigned)((words + 255) / 256)), blk(256);
   if (dtype == SLM_BF16)
@@ -516,6 +518,7 @@ SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream) {
       (!a->workspace || a->workspace_bytes < pl.part_bytes + pl.aperm_bytes))
     return SLM_ERR_WORKSPACE;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hip_clear_error();
 
   GemmKParams kp;
   kp.a = a->a; kp.lda = a->lda;
