@@ -48,6 +48,8 @@ typedef enum slm_dtype {
 
 SLM_API const char* slm_status_string(int status);
 SLM_API const char* slm_version(void);
+/* hipGetErrorString of the last launch status seen by this thread (detail for SLM_ERR_LAUNCH). */
+SLM_API const char* slm_last_hip_error(void);
 
 /* ========================================================================== */
 /* 1. Paged-KV varlen attention (prefill / chunked prefill / decode / verify) */

@@ -62,10 +62,16 @@ def lib() -> C.CDLL:
         raise SlmError(
             f"{LIB_PATH} not found: build it with `python -m scalellm_amd.build` "
             "(hipcc --offload-arch=gfx950). scalellm_amd has no CPU / PyTorch fallback.")
+    # ONE HIP runtime per process: torch ships its own libamdhip64.so.7 (same SONAME as
+    # /opt/rocm's).  Importing torch first makes libslm_hip.so bind to the runtime torch already
+    # loaded -- the one that owns the device context, streams and allocations we are handed.
+    # (Loaded the other way round, kernels launch on a second runtime that sees no device.)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.slm_status_string.restype = C.c_char_p
     L.slm_status_string.argtypes = [C.c_int]
     L.slm_version.restype = C.c_char_p
+    L.slm_last_hip_error.restype = C.c_char_p
     L.slm_paged_kv_varlen_mha.restype = C.c_int
     L.slm_paged_kv_varlen_mha.argtypes = [C.POINTER(AttnArgs), C.c_void_p]
     L.slm_paged_kv_varlen_mha_workspace_bytes.restype = C.c_size_t
@@ -106,4 +112,5 @@ def lib() -> C.CDLL:
 
 def check(rc: int, what: str) -> None:
     if rc != 0:
-        raise SlmError(f"{what} failed: {lib().slm_status_string(rc).decode()} ({rc})")
+        detail = f" [{lib().slm_last_hip_error().decode()}]" if rc == -4 else ""
+        raise SlmError(f"{what} failed: {lib().slm_status_string(rc).decode()} ({rc}){detail}")

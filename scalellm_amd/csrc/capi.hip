@@ -15,6 +15,10 @@ SLM_API const char* slm_status_string(int status) {
   }
 }
 
+SLM_API const char* slm_last_hip_error(void) {
+  return hipGetErrorString((hipError_t)slm::hip_last_error_slot());
+}
+
 SLM_API const char* slm_version(void) { return "slm_hip 0.1.0 (gfx950)"; }
 
 }  // extern "C"

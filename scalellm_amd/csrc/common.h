@@ -105,8 +105,16 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // hipGetLastError() is per-thread sticky state shared with every other HIP user in the process
 // (torch, RCCL): clear stale errors when an entry point starts, so that hip_check_launch()
 // reports only OUR launch.
+inline int& hip_last_error_slot() {
+  static thread_local int e = 0;
+  return e;
+}
 inline void hip_clear_error() { (void)hipGetLastError(); }
-inline int hip_check_launch() { return hipGetLastError() == hipSuccess ? SLM_OK : SLM_ERR_LAUNCH; }
+inline int hip_check_launch() {
+  const hipError_t e = hipGetLastError();
+  hip_last_error_slot() = (int)e;
+  return e == hipSuccess ? SLM_OK : SLM_ERR_LAUNCH;
+}
 
 inline bool is_pow2(int64_t x) { return x > 0 && (x & (x - 1)) == 0; }
 inline int ilog2(int64_t x) {
