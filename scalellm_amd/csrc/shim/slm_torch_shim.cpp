@@ -1,0 +1,338 @@
+// slm_torch_shim.cpp -- see slm_torch_shim.h.  Pure host code (g++), no device code: tensors are
+// unpacked to (pointer, strides, sizes) and handed to the C ABI on torch's current HIP stream.
+#include "slm_torch_shim.h"
+
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+#include <stdexcept>
+#include <unordered_map>
+
+#include "slm_hip.h"
+
+namespace {
+
+int dtype_code(const torch::Tensor& t) {
+  if (t.scalar_type() == torch::kBFloat16) return SLM_BF16;
+  if (t.scalar_type() == torch::kHalf) return SLM_F16;
+  // same restriction as the reference's DISPATCH_TORCH_DTYPE (common/static_dispatch.h:16-27)
+  TORCH_CHECK(false, "slm: only fp16 / bf16 tensors are supported, got ", t.scalar_type());
+  return -1;
+}
+
+void* current_stream(const torch::Tensor& t) {
+  return c10::hip::getCurrentHIPStream(t.device().index()).stream();
+}
+
+void check(int rc, const char* what) {
+  TORCH_CHECK(rc == SLM_OK, what, " failed: ", slm_status_string(rc), " (", rc, ")",
+              rc == SLM_ERR_LAUNCH ? slm_last_hip_error() : "");
+}
+
+// one growable scratch buffer per device (split-KV / split-K partials); grown outside capture
+std::mutex g_ws_mu;
+std::unordered_map<int, torch::Tensor> g_ws;
+torch::Tensor g_user_ws;
+
+torch::Tensor workspace_for(const torch::Tensor& like, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  if (g_user_ws.defined() && g_user_ws.device() == like.device() &&
+      static_cast<size_t>(g_user_ws.nbytes()) >= bytes)
+    return g_user_ws;
+  auto& ws = g_ws[like.device().index()];
+  if (!ws.defined() || static_cast<size_t>(ws.nbytes()) < bytes) {
+    ws = torch::empty({static_cast<int64_t>(std::max<size_t>(bytes, 1 << 20))},
+                      torch::dtype(torch::kUInt8).device(like.device()));
+  }
+  return ws;
+}
+
+}  // namespace
+
+namespace llm {
+
+void paged_kv_varlen_mha(torch::Tensor& out, const torch::Tensor& query,
+                         const torch::Tensor& key_cache, const torch::Tensor& value_cache,
+                         const torch::Tensor& q_cu_lens, const torch::Tensor& kv_cu_lens,
+                         const torch::Tensor& block_table, const torch::Tensor& block_cu_lens,
+                         const std::optional<torch::Tensor>& alibi_slopes, int block_size,
+                         int max_q_len, int max_kv_len, float sm_scale, float logits_soft_cap,
+                         int sliding_window) {
+  c10::hip::OptionalHIPGuard guard(query.device());
+  slm_attn_args a{};
+  a.out = out.mutable_data_ptr();
+  a.query = query.const_data_ptr();
+  a.key_cache = key_cache.const_data_ptr();
+  a.value_cache = value_cache.const_data_ptr();
+  // strides in elements, last dim contiguous (attn_api.cpp:38-45)
+  a.o_stride[0] = out.stride(0); a.o_stride[1] = out.stride(1);
+  a.q_stride[0] = query.stride(0); a.q_stride[1] = query.stride(1);
+  a.k_stride[0] = key_cache.stride(0); a.k_stride[1] = key_cache.stride(1);
+  a.v_stride[0] = value_cache.stride(0); a.v_stride[1] = value_cache.stride(1);
+  a.q_cu_lens = q_cu_lens.const_data_ptr<int32_t>();
+  a.kv_cu_lens = kv_cu_lens.const_data_ptr<int32_t>();
+  a.block_table = block_table.const_data_ptr<int32_t>();
+  a.block_cu_lens = block_cu_lens.const_data_ptr<int32_t>();
+  a.alibi_slopes = alibi_slopes.has_value() ? alibi_slopes.value().const_data_ptr<float>() : nullptr;
+  a.dtype = dtype_code(query);
+  a.batch_size = static_cast<int32_t>(q_cu_lens.size(0) - 1);
+  a.n_tokens = static_cast<int32_t>(query.size(0));
+  a.n_heads = static_cast<int32_t>(query.size(-2));
+  a.n_kv_heads = static_cast<int32_t>(key_cache.size(-2));
+  a.head_dim = static_cast<int32_t>(query.size(-1));
+  a.block_size = block_size;
+  a.max_q_len = max_q_len;
+  a.max_kv_len = max_kv_len;
+  a.sm_scale = sm_scale;
+  a.logits_soft_cap = logits_soft_cap;
+  a.sliding_window = sliding_window;
+  a.num_splits = 0;
+  if (a.n_tokens == 0 || a.batch_size == 0) return;
+  const size_t need = slm_paged_kv_varlen_mha_workspace_bytes(&a);
+  torch::Tensor ws;
+  if (need > 0) {
+    ws = workspace_for(query, need);
+    a.workspace = ws.mutable_data_ptr();
+    a.workspace_bytes = ws.nbytes();
+  }
+  check(slm_paged_kv_varlen_mha(&a, current_stream(query)), "slm_paged_kv_varlen_mha");
+}
+
+int64_t paged_kv_varlen_mha_workspace_size(int64_t n_tokens, int64_t n_heads, int64_t head_dim) {
+  return n_tokens * n_heads * 256 * (head_dim + 2) * static_cast<int64_t>(sizeof(float));
+}
+
+void paged_kv_varlen_mha_set_workspace(const torch::Tensor& workspace) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  g_user_ws = workspace;
+}
+
+namespace kernel {
+
+void set_kv_cache(const torch::Tensor& slot_ids, const torch::Tensor& keys,
+                  const torch::Tensor& values, torch::Tensor& key_cache,
+                  torch::Tensor& value_cache) {
+  // keys and values contiguous at n_kv_heads and head_dim dims (kv_cache_kernels.cu:50-51)
+  TORCH_CHECK(keys.stride(-1) == 1 && keys.stride(-2) == keys.size(-1));
+  TORCH_CHECK(values.stride(-1) == 1 && values.stride(-2) == values.size(-1));
+  c10::hip::OptionalHIPGuard guard(keys.device());
+  check(slm_set_kv_cache(slot_ids.const_data_ptr<int32_t>(), keys.const_data_ptr(),
+                         values.const_data_ptr(), keys.stride(-3), values.stride(-3),
+                         key_cache.mutable_data_ptr(), value_cache.mutable_data_ptr(),
+                         keys.size(-3), static_cast<int32_t>(keys.size(-2)),
+                         static_cast<int32_t>(keys.size(-1)), dtype_code(keys),
+                         current_stream(keys)),
+        "slm_set_kv_cache");
+}
+
+void apply_rotary_pos_emb_and_append(torch::Tensor& query, torch::Tensor& key,
+                                     const torch::Tensor& value, const torch::Tensor& positions,
+                                     const torch::Tensor& cos_sin, int rotary_dim, bool interleaved,
+                                     const torch::Tensor& slot_ids, torch::Tensor& key_cache,
+                                     torch::Tensor& value_cache) {
+  c10::hip::OptionalHIPGuard guard(query.device());
+  const bool append = slot_ids.defined() && slot_ids.numel() > 0;
+  const bool f32 = cos_sin.scalar_type() == torch::kFloat;
+  TORCH_CHECK(f32 || cos_sin.scalar_type() == query.scalar_type());
+  check(slm_rope_kv_append(query.mutable_data_ptr(), query.stride(0), key.mutable_data_ptr(),
+                           key.stride(0), append ? value.const_data_ptr() : nullptr,
+                           append ? value.stride(0) : 0, positions.const_data_ptr<int32_t>(),
+                           cos_sin.const_data_ptr(), f32 ? 1 : 0, rotary_dim, interleaved ? 1 : 0,
+                           append ? slot_ids.const_data_ptr<int32_t>() : nullptr,
+                           append ? key_cache.mutable_data_ptr() : nullptr,
+                           append ? value_cache.mutable_data_ptr() : nullptr, query.size(0),
+                           static_cast<int32_t>(query.size(1)), static_cast<int32_t>(key.size(1)),
+                           static_cast<int32_t>(query.size(2)), dtype_code(query),
+                           current_stream(query)),
+        "slm_rope_kv_append");
+}
+
+void apply_rotary_pos_emb(torch::Tensor& query, torch::Tensor& key, const torch::Tensor& positions,
+                          const torch::Tensor& cos_sin, int rotary_dim, bool interleaved) {
+  torch::Tensor none;
+  apply_rotary_pos_emb_and_append(query, key, none, positions, cos_sin, rotary_dim, interleaved,
+                                  none, none, none);
+}
+
+void rms_norm(torch::Tensor& out, torch::Tensor input, torch::Tensor weight, float epsilon) {
+  c10::hip::OptionalHIPGuard guard(input.device());
+  const int64_t dim = input.size(-1);
+  check(slm_rms_norm(out.mutable_data_ptr(), input.const_data_ptr(), weight.const_data_ptr(),
+                     nullptr, input.numel() / dim, dim, epsilon, dtype_code(input),
+                     current_stream(input)),
+        "slm_rms_norm");
+}
+
+void rms_norm_residual(torch::Tensor& out, torch::Tensor& residual, torch::Tensor input,
+                       torch::Tensor weight, float epsilon) {
+  c10::hip::OptionalHIPGuard guard(input.device());
+  const int64_t dim = input.size(-1);
+  check(slm_rms_norm(out.mutable_data_ptr(), input.const_data_ptr(), weight.const_data_ptr(),
+                     residual.mutable_data_ptr(), input.numel() / dim, dim, epsilon,
+                     dtype_code(input), current_stream(input)),
+        "slm_rms_norm");
+}
+
+void silu_and_mul(torch::Tensor& out, torch::Tensor input) {
+  c10::hip::OptionalHIPGuard guard(input.device());
+  const int64_t d = input.size(-1) / 2;
+  check(slm_silu_mul(out.mutable_data_ptr(), input.const_data_ptr(), input.numel() / (2 * d), d,
+                     dtype_code(input), current_stream(input)),
+        "slm_silu_mul");
+}
+
+}  // namespace kernel
+}  // namespace llm
+
+namespace slm {
+
+W4Linear::W4Linear(const std::string& quant_method, const torch::Tensor& qweight,
+                   const torch::Tensor& qzeros, const torch::Tensor& scales,
+                   const std::optional<torch::Tensor>& g_idx, int64_t group_size) {
+  const bool awq = quant_method == "awq";
+  TORCH_CHECK(awq || quant_method == "gptq", "quant_method must be awq or gptq");
+  c10::hip::OptionalHIPGuard guard(qweight.device());
+  K_ = awq ? qweight.size(0) : qweight.size(0) * 8;
+  N_ = awq ? qweight.size(1) * 8 : qweight.size(1);
+  group_size_ = group_size > 0 ? group_size : K_;
+  dtype_ = scales.scalar_type();
+  if (!awq && g_idx.has_value() && g_idx->numel() > 0) {
+    // act-order: rows sorted by group, like qlinear_gptq_marlin_impl.cpp:41-71
+    const auto gi = g_idx->to(torch::kLong);
+    const auto trivial =
+        torch::arange(K_, torch::dtype(torch::kLong).device(gi.device())).floor_divide(group_size_);
+    if (!torch::equal(gi, trivial)) {
+      const auto perm = torch::argsort(gi, /*stable=*/true, /*dim=*/0, /*descending=*/false);
+      TORCH_CHECK(torch::equal(gi.index({perm}), trivial),
+                  "act-order g_idx with uneven groups is not supported");
+      perm_ = perm.to(torch::kInt).contiguous();
+    }
+  }
+  const size_t wb = slm_w4_packed_weight_bytes(K_, N_);
+  const size_t sb = slm_w4_packed_sz_bytes(K_, N_, group_size_);
+  TORCH_CHECK(wb > 0 && sb > 0, "unsupported int4 shape K=", K_, " N=", N_, " group=", group_size_);
+  const auto iopt = torch::dtype(torch::kInt).device(qweight.device());
+  wq_ = torch::empty({static_cast<int64_t>(wb / 4)}, iopt);
+  sz_ = torch::empty({static_cast<int64_t>(sb / 4)}, iopt);
+  const auto qw = qweight.contiguous(), qz = qzeros.contiguous(), sc = scales.contiguous();
+  check(slm_w4_prepack(awq ? SLM_W4_AWQ : SLM_W4_GPTQ, qw.const_data_ptr<int32_t>(),
+                       qz.const_data_ptr<int32_t>(), sc.const_data_ptr(),
+                       perm_.defined() ? perm_.const_data_ptr<int32_t>() : nullptr, K_, N_,
+                       group_size_, dtype_code(sc), wq_.mutable_data_ptr(), sz_.mutable_data_ptr(),
+                       current_stream(qw)),
+        "slm_w4_prepack");
+}
+
+torch::Tensor W4Linear::forward(const torch::Tensor& input, const std::optional<torch::Tensor>& bias,
+                                std::optional<torch::Tensor> out) const {
+  c10::hip::OptionalHIPGuard guard(input.device());
+  const auto a = input.reshape({-1, input.size(-1)});
+  TORCH_CHECK(a.size(1) == K_ && a.stride(1) == 1 && a.scalar_type() == dtype_);
+  torch::Tensor c = out.has_value() ? *out : torch::empty({a.size(0), N_}, a.options());
+  slm_w4_gemm_args g{};
+  g.a = a.const_data_ptr();
+  g.wq = wq_.const_data_ptr();
+  g.sz = sz_.const_data_ptr();
+  g.perm = perm_.defined() ? perm_.const_data_ptr<int32_t>() : nullptr;
+  g.bias = bias.has_value() && bias->defined() ? bias->const_data_ptr() : nullptr;
+  g.c = c.mutable_data_ptr();
+  g.M = a.size(0); g.K = K_; g.N = N_;
+  g.lda = a.stride(0); g.ldc = c.stride(0);
+  g.group_size = group_size_;
+  g.dtype = dtype_code(a);
+  if (g.M == 0) return c;
+  const size_t need = slm_w4a16_gemm_workspace_bytes(&g);
+  torch::Tensor ws;
+  if (need > 0) {
+    ws = workspace_for(a, need);
+    g.workspace = ws.mutable_data_ptr();
+    g.workspace_bytes = ws.nbytes();
+  }
+  check(slm_w4a16_gemm(&g, current_stream(a)), "slm_w4a16_gemm");
+  return c;
+}
+
+torch::Tensor W4Linear::dequantize() const {
+  c10::hip::OptionalHIPGuard guard(wq_.device());
+  auto w = torch::empty({K_, N_}, torch::dtype(dtype_).device(wq_.device()));
+  check(slm_w4_dequant(wq_.const_data_ptr(), sz_.const_data_ptr(), K_, N_, group_size_,
+                       dtype_ == torch::kBFloat16 ? SLM_BF16 : SLM_F16, w.mutable_data_ptr(),
+                       current_stream(wq_)),
+        "slm_w4_dequant");
+  return w;
+}
+
+// --------------------------------------------------------------------------------------------
+// ProcessGroupRCCL
+// --------------------------------------------------------------------------------------------
+namespace {
+ncclDataType_t to_nccl(const torch::Tensor& t) {
+  switch (t.scalar_type()) {
+    case torch::kFloat: return ncclFloat;
+    case torch::kHalf: return ncclHalf;
+    case torch::kBFloat16: return ncclBfloat16;
+    case torch::kInt: return ncclInt32;
+    case torch::kLong: return ncclInt64;
+    case torch::kDouble: return ncclDouble;
+    case torch::kByte: return ncclUint8;
+    default: TORCH_CHECK(false, "unsupported dtype for RCCL: ", t.scalar_type());
+  }
+  return ncclFloat;
+}
+void nccl_check(ncclResult_t r, const char* what) {
+  TORCH_CHECK(r == ncclSuccess, what, " failed: ", ncclGetErrorString(r));
+}
+void check_input(const torch::Tensor& t) {  // process_group.cpp:59-63
+  TORCH_CHECK(t.is_cuda() && t.is_contiguous(), "tensor must be a contiguous device tensor");
+}
+}  // namespace
+
+std::vector<std::unique_ptr<ProcessGroupRCCL>> ProcessGroupRCCL::create_process_groups(
+    const std::vector<torch::Device>& devices) {
+  std::vector<int> ids;
+  for (const auto& d : devices) ids.push_back(d.index());
+  std::vector<ncclComm_t> comms(devices.size());
+  nccl_check(ncclCommInitAll(comms.data(), static_cast<int>(devices.size()), ids.data()),
+             "ncclCommInitAll");
+  std::vector<std::unique_ptr<ProcessGroupRCCL>> out;
+  for (size_t i = 0; i < devices.size(); ++i)
+    out.emplace_back(new ProcessGroupRCCL(static_cast<int>(i), static_cast<int>(devices.size()),
+                                          devices[i], comms[i]));
+  return out;
+}
+
+ProcessGroupRCCL::~ProcessGroupRCCL() {
+  if (comm_) ncclCommDestroy(static_cast<ncclComm_t>(comm_));
+}
+
+void ProcessGroupRCCL::allreduce(torch::Tensor& input) const {
+  check_input(input);
+  c10::hip::OptionalHIPGuard guard(device_);
+  nccl_check(ncclAllReduce(input.const_data_ptr(), input.mutable_data_ptr(), input.numel(),
+                           to_nccl(input), ncclSum, static_cast<ncclComm_t>(comm_),
+                           c10::hip::getCurrentHIPStream(device_.index()).stream()),
+             "ncclAllReduce");
+}
+
+void ProcessGroupRCCL::allgather(const torch::Tensor& input, torch::Tensor& outputs) const {
+  check_input(input);
+  check_input(outputs);
+  c10::hip::OptionalHIPGuard guard(device_);
+  nccl_check(ncclAllGather(input.const_data_ptr(), outputs.mutable_data_ptr(), input.numel(),
+                           to_nccl(input), static_cast<ncclComm_t>(comm_),
+                           c10::hip::getCurrentHIPStream(device_.index()).stream()),
+             "ncclAllGather");
+}
+
+void ProcessGroupRCCL::allgather(const torch::Tensor& input,
+                                 std::vector<torch::Tensor>& outputs) const {
+  TORCH_CHECK(static_cast<int>(outputs.size()) == world_size_);
+  auto flat = torch::empty({world_size_ * input.numel()}, input.options());
+  allgather(input, flat);
+  for (int r = 0; r < world_size_; ++r)
+    outputs[r].copy_(flat.narrow(0, r * input.numel(), input.numel()).view_as(outputs[r]));
+}
+
+}  // namespace slm

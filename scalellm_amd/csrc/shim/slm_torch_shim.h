@@ -1,0 +1,117 @@
+// slm_torch_shim.h -- libtorch adapter: the reference's C++ operator signatures on top of the
+// C-ABI HIP kernel library (include/slm_hip.h).  A ScaleLLM build links this instead of
+// src/kernels/attention, src/kernels/kv_cache_kernels.cu, src/kernels/pos_embedding_kernels.cu and
+// src/kernels/quantization/marlin; src/layers/** then compiles unchanged.
+//
+// Signatures below are the reference's, verbatim in types / order / meaning:
+//   llm::paged_kv_varlen_mha           src/kernels/attention/attn_api.h:12-27
+//   llm::kernel::set_kv_cache          src/kernels/kv_cache_kernels.h:6-11
+//   llm::kernel::apply_rotary_pos_emb  src/kernels/pos_embedding_kernels.h
+// The int4 path is offered at the layer boundary the survey recommends (ParallelLinearImpl,
+// src/layers/linear/parallel_linear.h:17-37): slm::W4Linear owns the MFMA-native packed layout
+// and is what a QLinearHipImpl subclass wraps (INTEGRATION.md shows the 40-line subclass).
+// slm::ProcessGroupRCCL implements llm::ProcessGroup's contract (process_group.h:10-60) on RCCL.
+#pragma once
+#include <torch/torch.h>
+
+#include <memory>
+#include <optional>
+#include <vector>
+
+namespace llm {
+
+void paged_kv_varlen_mha(torch::Tensor& out,                // [n_tokens, n_heads, head_dim]
+                         const torch::Tensor& query,        // [n_tokens, n_heads, head_dim]
+                         const torch::Tensor& key_cache,    // [n_slots, n_kv_heads, head_dim]
+                         const torch::Tensor& value_cache,  // [n_slots, n_kv_heads, head_dim]
+                         const torch::Tensor& q_cu_lens,    // [batch + 1]
+                         const torch::Tensor& kv_cu_lens,   // [batch + 1]
+                         const torch::Tensor& block_table,
+                         const torch::Tensor& block_cu_lens,                // [batch + 1]
+                         const std::optional<torch::Tensor>& alibi_slopes,  // [n_heads]
+                         int block_size, int max_q_len, int max_kv_len, float sm_scale,
+                         float logits_soft_cap, int sliding_window);
+
+// AttentionHandler::get_estimate_workspace_size / set_workspace (handler.h:40-47) hooks: the
+// split-KV scratch.  Without a workspace the shim keeps one growable buffer per device.
+int64_t paged_kv_varlen_mha_workspace_size(int64_t n_tokens, int64_t n_heads, int64_t head_dim);
+void paged_kv_varlen_mha_set_workspace(const torch::Tensor& workspace);
+
+namespace kernel {
+
+void set_kv_cache(const torch::Tensor& slot_ids,  // [n_tokens]
+                  const torch::Tensor& keys,      // [n_tokens, n_kv_heads, head_dim]
+                  const torch::Tensor& values,    // [n_tokens, n_kv_heads, head_dim]
+                  torch::Tensor& key_cache,       // [n_slots, n_kv_heads, head_dim]
+                  torch::Tensor& value_cache);
+
+void apply_rotary_pos_emb(torch::Tensor& query,            // [n_tokens, n_heads, head_dim]
+                          torch::Tensor& key,              // [n_tokens, n_kv_heads, head_dim]
+                          const torch::Tensor& positions,  // [n_tokens]
+                          const torch::Tensor& cos_sin,    // [max_positions, 2, rotary_dim/2]
+                          int rotary_dim, bool interleaved);
+
+// fused form used by a HipAttnHandler: rope + KV append in one launch (attention.cpp:36-39)
+void apply_rotary_pos_emb_and_append(torch::Tensor& query, torch::Tensor& key,
+                                     const torch::Tensor& value, const torch::Tensor& positions,
+                                     const torch::Tensor& cos_sin, int rotary_dim, bool interleaved,
+                                     const torch::Tensor& slot_ids, torch::Tensor& key_cache,
+                                     torch::Tensor& value_cache);
+
+void rms_norm(torch::Tensor& out, torch::Tensor input, torch::Tensor weight, float epsilon);
+void rms_norm_residual(torch::Tensor& out, torch::Tensor& residual, torch::Tensor input,
+                       torch::Tensor weight, float epsilon);
+void silu_and_mul(torch::Tensor& out, torch::Tensor input);
+
+}  // namespace kernel
+}  // namespace llm
+
+namespace slm {
+
+// int4 linear in the library's packed layout.  Built once from CHECKPOINT-format tensors (the
+// same tensors the reference's load_state_dict collects), then forward() = one GEMM launch.
+class W4Linear {
+ public:
+  // quant_method "awq": qweight [K, N/8], qzeros [G, N/8] (AWQ interleave), scales [G, N]
+  // quant_method "gptq": qweight [K/8, N], qzeros [G, N/8], scales [G, N], optional g_idx [K]
+  W4Linear(const std::string& quant_method, const torch::Tensor& qweight,
+           const torch::Tensor& qzeros, const torch::Tensor& scales,
+           const std::optional<torch::Tensor>& g_idx, int64_t group_size);
+
+  // C[M, N] = A[M, K] . dequant(W) (+ bias); `out` may be pre-allocated
+  torch::Tensor forward(const torch::Tensor& input, const std::optional<torch::Tensor>& bias,
+                        std::optional<torch::Tensor> out = std::nullopt) const;
+  torch::Tensor dequantize() const;  // dense [K, N] (debug / parity)
+
+  int64_t in_features() const { return K_; }
+  int64_t out_features() const { return N_; }
+
+ private:
+  torch::Tensor wq_, sz_, perm_;
+  int64_t K_ = 0, N_ = 0, group_size_ = 0;
+  torch::ScalarType dtype_;
+};
+
+// llm::ProcessGroup's contract over RCCL: one communicator per local GPU created together
+// (ncclCommInitAll, as process_group.cpp:98-123), collectives on the CURRENT stream of the
+// tensor's device so they are captured into hipGraphs with the kernels around them.
+class ProcessGroupRCCL {
+ public:
+  static std::vector<std::unique_ptr<ProcessGroupRCCL>> create_process_groups(
+      const std::vector<torch::Device>& devices);
+  ~ProcessGroupRCCL();
+  int rank() const { return rank_; }
+  int world_size() const { return world_size_; }
+  void allreduce(torch::Tensor& input) const;
+  void allgather(const torch::Tensor& input, std::vector<torch::Tensor>& outputs) const;
+  void allgather(const torch::Tensor& input, torch::Tensor& outputs) const;
+
+ private:
+  ProcessGroupRCCL(int rank, int world_size, torch::Device device, void* comm)
+      : rank_(rank), world_size_(world_size), device_(device), comm_(comm) {}
+  int rank_, world_size_;
+  torch::Device device_;
+  void* comm_;  // ncclComm_t
+};
+
+}  // namespace slm

@@ -1,0 +1,154 @@
+"""CPU tests of the C-ABI boundary: the library loads without a GPU, exports every symbol that
+include/slm_hip.h declares, validates arguments before touching the device, and its host-side
+planning entry points (workspace sizes, split heuristics) behave."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from scalellm_amd import _lib
+from scalellm_amd._lib import AttnArgs, W4GemmArgs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "slm_hip.h")
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"SLM_API\s+[\w\s\*]+?\b(slm_\w+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_entry_points():
+    syms = _declared_symbols()
+    for must in ("slm_paged_kv_varlen_mha", "slm_set_kv_cache", "slm_w4_prepack", "slm_w4a16_gemm",
+                 "slm_rms_norm", "slm_rope_kv_append", "slm_silu_mul"):
+        assert must in syms
+    assert len(syms) >= 15
+
+
+def test_library_exports_every_declared_symbol():
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = set(re.findall(r"\sT\s+(slm_\w+)", out))
+    missing = [s for s in _declared_symbols() if s not in exported]
+    assert not missing, f"declared in slm_hip.h but not exported: {missing}"
+    # nothing else leaks out of the library (fvisibility=hidden)
+    assert exported == set(_declared_symbols())
+
+
+def test_library_loads_without_gpu_and_reports_version():
+    L = _lib.lib()
+    assert b"gfx950" in L.slm_version()
+    assert L.slm_status_string(0) == b"ok"
+    assert L.slm_status_string(-3) == b"workspace missing or too small"
+
+
+def _attn(bs, n_tokens, heads=32, kv_heads=8, d=128, block=16, max_kv=4096, max_q=1, splits=0):
+    a = AttnArgs()
+    a.dtype, a.batch_size, a.n_tokens = 1, bs, n_tokens
+    a.n_heads, a.n_kv_heads, a.head_dim, a.block_size = heads, kv_heads, d, block
+    a.max_q_len, a.max_kv_len, a.num_splits = max_q, max_kv, splits
+    a.k_stride[0], a.v_stride[0] = kv_heads * d, kv_heads * d
+    return a
+
+
+def test_split_kv_heuristic_host_side():
+    L = _lib.lib()
+    for k in ("SLM_ATTN_SPLITS", "SLM_ATTN_NW", "SLM_ATTN_HGW"):
+        os.environ.pop(k, None)
+    big = _attn(256, 256)
+    assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(big)) == 1
+    assert L.slm_paged_kv_varlen_mha_workspace_bytes(C.byref(big)) == 0
+    mid = _attn(32, 32)
+    s_mid = L.slm_paged_kv_varlen_mha_auto_splits(C.byref(mid))
+    assert 4 <= s_mid <= 16
+    one = _attn(1, 1)
+    s_one = L.slm_paged_kv_varlen_mha_auto_splits(C.byref(one))
+    assert 16 <= s_one <= 64  # >= 64 KV rows per split
+    need = L.slm_paged_kv_varlen_mha_workspace_bytes(C.byref(one))
+    assert need == 1 * 32 * s_one * (128 + 2) * 4
+    short = _attn(1, 1, max_kv=100)
+    assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(short)) == 1
+    prefill = _attn(2, 4096, max_q=2048)
+    assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(prefill)) == 1
+    forced = _attn(256, 256, splits=7)
+    assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(forced)) == 7
+
+
+@pytest.mark.parametrize("mut,code", [
+    (dict(heads=30), -1),          # n_heads % n_kv_heads
+    (dict(d=7), -2),               # head_dim % 8
+    (dict(d=512), -2),             # head_dim > 256
+    (dict(block=6), -1),           # not a power of two (mha_params.h:71-74)
+])
+def test_attention_argument_validation_precedes_any_launch(mut, code):
+    L = _lib.lib()
+    a = _attn(1, 1, **mut)
+    assert L.slm_paged_kv_varlen_mha(C.byref(a), None) == code
+    assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(a)) == 0
+
+
+def test_attention_null_pointers_and_alignment_rejected():
+    L = _lib.lib()
+    a = _attn(1, 1)
+    assert L.slm_paged_kv_varlen_mha(C.byref(a), None) == -1  # null tensors
+    buf = (C.c_char * 4096)()
+    base = C.addressof(buf)
+    base = (base + 15) & ~15
+    for f in ("out", "query", "key_cache", "value_cache", "q_cu_lens", "kv_cu_lens", "block_table",
+              "block_cu_lens"):
+        setattr(a, f, base)
+    a.o_stride[0] = a.q_stride[0] = 32 * 128
+    a.o_stride[1] = a.q_stride[1] = 128
+    a.k_stride[1] = a.v_stride[1] = 128
+    a.query = base + 2  # misaligned
+    assert L.slm_paged_kv_varlen_mha(C.byref(a), None) == -5
+
+
+def test_w4_host_side_planning_and_validation():
+    L = _lib.lib()
+    assert L.slm_w4_packed_weight_bytes(4096, 4096) == 4096 * 4096 // 2
+    assert L.slm_w4_packed_weight_bytes(4096, 4100) == 0  # N % 32
+    assert L.slm_w4_packed_sz_bytes(4096, 6144, 128) == 32 * 6144 * 4
+    g = W4GemmArgs()
+    g.M, g.K, g.N, g.lda, g.ldc, g.group_size, g.dtype = 32, 4096, 4096, 4096, 4096, 128, 1
+    os.environ.pop("SLM_W4_SPLITK", None)
+    ws = L.slm_w4a16_gemm_workspace_bytes(C.byref(g))
+    assert ws % (32 * 4096 * 4) == 0  # split-K partials: whole [M, N] fp32 slabs (or none)
+    g.group_size = 48
+    assert L.slm_w4a16_gemm(C.byref(g), None) == -2
+    g.group_size, g.K = 128, 4000
+    assert L.slm_w4a16_gemm(C.byref(g), None) == -2
+    assert L.slm_w4_prepack(0, None, None, None, None, 128, 64, 128, 1, None, None, None) == -1
+    assert L.slm_set_kv_cache(None, None, None, 0, 0, None, None, 0, 8, 128, 1, None) == 0  # empty
+    assert L.slm_set_kv_cache(None, None, None, 0, 0, None, None, 3, 8, 128, 1, None) == -1
+
+
+def test_python_mirror_fails_loudly_on_cpu_tensors():
+    """No CPU / PyTorch fallback anywhere in the product path."""
+    from scalellm_amd import kernels
+    from scalellm_amd._lib import SlmError
+    q = torch.zeros(1, 8, 64, dtype=torch.float16)
+    kc = torch.zeros(16, 2, 64, dtype=torch.float16)
+    cu = torch.tensor([0, 1], dtype=torch.int32)
+    with pytest.raises(SlmError):
+        kernels.paged_kv_varlen_mha(q.clone(), q, kc, kc, cu, cu, cu[:1], cu, None, 8, 1, 1, 1.0)
+    with pytest.raises(SlmError):
+        kernels.set_kv_cache(cu[:1], kc[:1], kc[:1], kc, kc.clone())
+    with pytest.raises(SlmError):
+        kernels.rms_norm(torch.zeros(2, 64, dtype=torch.float16), torch.zeros(2, 64, dtype=torch.float16),
+                         torch.ones(64, dtype=torch.float16), 1e-5)
+
+
+def test_product_path_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under scalellm_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "scalellm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and \
+                    "libslm_oracle" not in txt, f"{f} references the oracle"

@@ -1,0 +1,38 @@
+"""CPU tests of the host-side logic: the synthetic engine-format input builder reproduces the
+reference's block-table / slot arithmetic (engine/batch.cpp:197-211, request/sequence.cpp:303-317)
+bit-exactly, and bench.py's algorithmic-byte model matches SURVEY 8d."""
+import numpy as np
+import torch
+
+from oracle import oracle
+
+
+def test_decode_inputs_follow_engine_format():
+    from scalellm_amd.decode import make_decode_inputs
+    for (bs, kv_len, B, q_len) in [(3, 37, 8, 1), (2, 64, 16, 1), (4, 50, 16, 5), (1, 1, 16, 1)]:
+        tokens, positions, p, n_blocks = make_decode_inputs(bs, kv_len, B, torch.device("cpu"), seed=3,
+                                                            q_len=q_len, vocab=1000)
+        nblk = (kv_len + B - 1) // B
+        table = p.block_tables.numpy()
+        assert table.shape == (bs * nblk,) and np.all(table % B == 0)  # first-slot ids
+        assert len(set(table.tolist())) == bs * nblk and table.min() >= B  # unique, block 0 unused
+        assert table.max() < n_blocks * B
+        assert np.array_equal(p.cu_block_lens.numpy(), np.arange(bs + 1) * nblk)
+        assert np.array_equal(p.q_cu_seq_lens.numpy(), np.arange(bs + 1) * q_len)
+        assert np.array_equal(p.kv_cu_seq_lens.numpy(), np.arange(bs + 1) * kv_len)
+        # new_cache_slots == slots of the LAST q_len positions of every sequence (batch.cpp:200-204)
+        all_slots = oracle.all_slots(table, p.cu_block_lens.numpy(), p.kv_cu_seq_lens.numpy(), B)
+        want = all_slots.reshape(bs, kv_len)[:, kv_len - q_len:].reshape(-1)
+        assert np.array_equal(p.new_cache_slots.numpy(), want)
+        assert np.array_equal(positions.numpy(), np.tile(np.arange(kv_len - q_len, kv_len), bs))
+        assert tokens.numel() == bs * q_len
+
+
+def test_algorithmic_bytes_match_survey():
+    import bench
+    # SURVEY 8d / BASELINE.md: 8B decode bs=256, L=4096, B=16 -> 4.2994 GB per layer call
+    b = bench.attn_algo_bytes(256, 4096, 32, 8, 128, 16)
+    assert b == 4294967296 + 4194304 + 4 * (256 * 256 + 3 * 257)
+    assert abs(b - 4.2994e9) < 1e6
+    assert abs(bench.attn_algo_bytes(32, 4096, 32, 8, 128, 16) - 537.5e6) < 1e6
+    assert abs(bench.attn_algo_bytes(1, 4096, 32, 8, 128, 16) - 16.8e6) < 1e5
