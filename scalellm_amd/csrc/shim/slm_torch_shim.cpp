@@ -2,8 +2,11 @@
 // unpacked to (pointer, strides, sizes) and handed to the C ABI on torch's current HIP stream.
 #include "slm_torch_shim.h"
 
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+// torch-ROCm tensors carry DeviceType "cuda" (HIP masquerades as CUDA), so the guard / stream
+// accessors are the *MasqueradingAsCUDA flavours -- what the reference's at::cuda::OptionalCUDAGuard
+// and at::cuda::getCurrentCUDAStream() resolve to in a hipified torch build.
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <rccl/rccl.h>
 
 #include <mutex>
@@ -23,7 +26,7 @@ int dtype_code(const torch::Tensor& t) {
 }
 
 void* current_stream(const torch::Tensor& t) {
-  return c10::hip::getCurrentHIPStream(t.device().index()).stream();
+  return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
 }
 
 void check(int rc, const char* what) {
@@ -60,7 +63,7 @@ void paged_kv_varlen_mha(torch::Tensor& out, const torch::Tensor& query,
                          const std::optional<torch::Tensor>& alibi_slopes, int block_size,
                          int max_q_len, int max_kv_len, float sm_scale, float logits_soft_cap,
                          int sliding_window) {
-  c10::hip::OptionalHIPGuard guard(query.device());
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(query.device());
   slm_attn_args a{};
   a.out = out.mutable_data_ptr();
   a.query = query.const_data_ptr();
@@ -117,7 +120,7 @@ void set_kv_cache(const torch::Tensor& slot_ids, const torch::Tensor& keys,
   // keys and values contiguous at n_kv_heads and head_dim dims (kv_cache_kernels.cu:50-51)
   TORCH_CHECK(keys.stride(-1) == 1 && keys.stride(-2) == keys.size(-1));
   TORCH_CHECK(values.stride(-1) == 1 && values.stride(-2) == values.size(-1));
-  c10::hip::OptionalHIPGuard guard(keys.device());
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(keys.device());
   check(slm_set_kv_cache(slot_ids.const_data_ptr<int32_t>(), keys.const_data_ptr(),
                          values.const_data_ptr(), keys.stride(-3), values.stride(-3),
                          key_cache.mutable_data_ptr(), value_cache.mutable_data_ptr(),
@@ -132,7 +135,7 @@ void apply_rotary_pos_emb_and_append(torch::Tensor& query, torch::Tensor& key,
                                      const torch::Tensor& cos_sin, int rotary_dim, bool interleaved,
                                      const torch::Tensor& slot_ids, torch::Tensor& key_cache,
                                      torch::Tensor& value_cache) {
-  c10::hip::OptionalHIPGuard guard(query.device());
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(query.device());
   const bool append = slot_ids.defined() && slot_ids.numel() > 0;
   const bool f32 = cos_sin.scalar_type() == torch::kFloat;
   TORCH_CHECK(f32 || cos_sin.scalar_type() == query.scalar_type());
@@ -157,7 +160,7 @@ void apply_rotary_pos_emb(torch::Tensor& query, torch::Tensor& key, const torch:
 }
 
 void rms_norm(torch::Tensor& out, torch::Tensor input, torch::Tensor weight, float epsilon) {
-  c10::hip::OptionalHIPGuard guard(input.device());
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input.device());
   const int64_t dim = input.size(-1);
   check(slm_rms_norm(out.mutable_data_ptr(), input.const_data_ptr(), weight.const_data_ptr(),
                      nullptr, input.numel() / dim, dim, epsilon, dtype_code(input),
@@ -167,7 +170,7 @@ void rms_norm(torch::Tensor& out, torch::Tensor input, torch::Tensor weight, flo
 
 void rms_norm_residual(torch::Tensor& out, torch::Tensor& residual, torch::Tensor input,
                        torch::Tensor weight, float epsilon) {
-  c10::hip::OptionalHIPGuard guard(input.device());
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input.device());
   const int64_t dim = input.size(-1);
   check(slm_rms_norm(out.mutable_data_ptr(), input.const_data_ptr(), weight.const_data_ptr(),
                      residual.mutable_data_ptr(), input.numel() / dim, dim, epsilon,
@@ -176,7 +179,7 @@ void rms_norm_residual(torch::Tensor& out, torch::Tensor& residual, torch::Tenso
 }
 
 void silu_and_mul(torch::Tensor& out, torch::Tensor input) {
-  c10::hip::OptionalHIPGuard guard(input.device());
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input.device());
   const int64_t d = input.size(-1) / 2;
   check(slm_silu_mul(out.mutable_data_ptr(), input.const_data_ptr(), input.numel() / (2 * d), d,
                      dtype_code(input), current_stream(input)),
@@ -193,7 +196,7 @@ W4Linear::W4Linear(const std::string& quant_method, const torch::Tensor& qweight
                    const std::optional<torch::Tensor>& g_idx, int64_t group_size) {
   const bool awq = quant_method == "awq";
   TORCH_CHECK(awq || quant_method == "gptq", "quant_method must be awq or gptq");
-  c10::hip::OptionalHIPGuard guard(qweight.device());
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(qweight.device());
   K_ = awq ? qweight.size(0) : qweight.size(0) * 8;
   N_ = awq ? qweight.size(1) * 8 : qweight.size(1);
   group_size_ = group_size > 0 ? group_size : K_;
@@ -227,7 +230,7 @@ W4Linear::W4Linear(const std::string& quant_method, const torch::Tensor& qweight
 
 torch::Tensor W4Linear::forward(const torch::Tensor& input, const std::optional<torch::Tensor>& bias,
                                 std::optional<torch::Tensor> out) const {
-  c10::hip::OptionalHIPGuard guard(input.device());
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input.device());
   const auto a = input.reshape({-1, input.size(-1)});
   TORCH_CHECK(a.size(1) == K_ && a.stride(1) == 1 && a.scalar_type() == dtype_);
   torch::Tensor c = out.has_value() ? *out : torch::empty({a.size(0), N_}, a.options());
@@ -255,7 +258,7 @@ torch::Tensor W4Linear::forward(const torch::Tensor& input, const std::optional<
 }
 
 torch::Tensor W4Linear::dequantize() const {
-  c10::hip::OptionalHIPGuard guard(wq_.device());
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(wq_.device());
   auto w = torch::empty({K_, N_}, torch::dtype(dtype_).device(wq_.device()));
   check(slm_w4_dequant(wq_.const_data_ptr(), sz_.const_data_ptr(), K_, N_, group_size_,
                        dtype_ == torch::kBFloat16 ? SLM_BF16 : SLM_F16, w.mutable_data_ptr(),
@@ -309,20 +312,20 @@ ProcessGroupRCCL::~ProcessGroupRCCL() {
 
 void ProcessGroupRCCL::allreduce(torch::Tensor& input) const {
   check_input(input);
-  c10::hip::OptionalHIPGuard guard(device_);
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_);
   nccl_check(ncclAllReduce(input.const_data_ptr(), input.mutable_data_ptr(), input.numel(),
                            to_nccl(input), ncclSum, static_cast<ncclComm_t>(comm_),
-                           c10::hip::getCurrentHIPStream(device_.index()).stream()),
+                           c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(device_.index()).stream()),
              "ncclAllReduce");
 }
 
 void ProcessGroupRCCL::allgather(const torch::Tensor& input, torch::Tensor& outputs) const {
   check_input(input);
   check_input(outputs);
-  c10::hip::OptionalHIPGuard guard(device_);
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_);
   nccl_check(ncclAllGather(input.const_data_ptr(), outputs.mutable_data_ptr(), input.numel(),
                            to_nccl(input), static_cast<ncclComm_t>(comm_),
-                           c10::hip::getCurrentHIPStream(device_.index()).stream()),
+                           c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(device_.index()).stream()),
              "ncclAllGather");
 }
 
