@@ -137,7 +137,7 @@ SLM_API int slm_set_kv_cache(const int32_t* slot_ids,  /* [n_tokens]           *
 /*            [0,2,4,6,1,3,5,7] nibble interleave, zero = stored;             */
 /*            scales  [G, N] T.                                               */
 /*    Output layout (owned by this library):                   */
-/*      wq  [N/32][K/64][64 lanes][4] uint32  -- lane l, word j holds the 8   */
+/*      wq  [K/64][N/32][64 lanes][4] uint32  -- lane l, word j holds the 8   */
 /*           nibbles n = 32*nt + (l&31), k = 64*kt + 16*j + 8*(l>>5) + p'     */
 /*           in a pair-interleaved nibble order (MFMA 32x32x16 B-fragment);   */
 /*      sz  [G][N] {scale, -zero*scale} as 2 x T  (fused scale/zero table);   */

@@ -5,10 +5,14 @@
 // marlin::awq_repack awq_repack.cu:191, permute_cols_kernel gptq_gemm.cu:69-118) with a layout
 // and a kernel designed for the CDNA4 matrix core (v_mfma_f32_32x32x16_{bf16,f16}, wave64):
 //
-//  packed weights  wq[N/32][K/64][64 lanes][4] u32: lane l, word j = the 8 weights
+//  packed weights  wq[K/64][N/32][64 lanes][4] u32 (kt-major): lane l, word j = the 8 weights
 //      n = 32*nt + (l & 31),  k = 64*kt + 16*j + 8*(l >> 5) + e,  e = 0..7
 //    i.e. exactly the B-operand fragment of one 32x32x16 MFMA, so a wave's 16-B/lane load is one
-//    contiguous KiB that feeds 4 MFMA k-steps with NO shuffle and NO LDS round trip.  Nibbles are
+//    contiguous KiB that feeds 4 MFMA k-steps with NO shuffle and NO LDS round trip.  kt-major
+//    order: at one k position the column tiles of all concurrently running waves are adjacent in
+//    memory, so the chip reads one dense N/32-KiB stripe at a time (an nt-major order makes every
+//    wave stream at a power-of-two stride from its neighbours: measured HBM-channel pile-up,
+//    ~2.2 TB/s ceiling).  Nibbles are
 //    pair-interleaved (bit 4i = e 2i, bit 16+4i = e 2i+1) so `(w >> 4i) & 0x000F000F | magic`
 //    yields a packed 16-bit pair directly (v_and_or_b32).
 //  scale/zero table sz[G][N] u32 = { scale : T, magic+zero : T }  (magic = 128 bf16 / 1024 fp16;
@@ -69,6 +73,29 @@ struct W4Dq<f16_tag> {
   }
 };
 
+// POST-scaled form (small-M kernels): the MFMA consumes the raw magic-number values (magic + q,
+// exact in T) -- unpack is 7 VALU per 8 weights instead of ~27 -- and the affine part is applied to
+// the per-group partial sums:  sum_k x_k s (q_k - z) = s * ( sum_k x_k (magic+q_k) - (magic+z) sum_k x_k ).
+template <typename T>
+struct W4Magic;
+template <>
+struct W4Magic<bf16_tag> {
+  static constexpr uint32_t bits = 0x43004300u;
+  static __device__ __forceinline__ void decode(uint32_t sz, float& s, float& zm) {
+    s = __builtin_bit_cast(float, sz << 16);
+    zm = __builtin_bit_cast(float, sz & 0xffff0000u);
+  }
+};
+template <>
+struct W4Magic<f16_tag> {
+  static constexpr uint32_t bits = 0x64006400u;
+  static __device__ __forceinline__ void decode(uint32_t sz, float& s, float& zm) {
+    const f16x2_t v = __builtin_bit_cast(f16x2_t, sz);
+    s = (float)v[0];
+    zm = (float)v[1];
+  }
+};
+
 __device__ __forceinline__ int awq_pos(int col_in_word) {  // [0,2,4,6,1,3,5,7] interleave
   return (col_in_word >> 1) + 4 * (col_in_word & 1);
 }
@@ -84,7 +111,7 @@ __global__ void __launch_bounds__(256) w4_prepack_weight_kernel(
   const int j = (int)(widx & 3);
   const int lane = (int)((widx >> 2) & 63);
   const int64_t tile = widx >> 8;
-  const int64_t kt = tile % (K / 64), nt = tile / (K / 64);
+  const int64_t nt = tile % (N / 32), kt = tile / (N / 32);  // kt-major: see layout note
   const int64_t n = nt * 32 + (lane & 31);
   const int64_t kb = kt * 64 + j * 16 + (lane >> 5) * 8;
   uint32_t out = 0;
@@ -129,7 +156,7 @@ __global__ void __launch_bounds__(256) w4_dequant_kernel(const uint32_t* __restr
   const int j = (int)(widx & 3);
   const int lane = (int)((widx >> 2) & 63);
   const int64_t tile = widx >> 8;
-  const int64_t kt = tile % (K / 64), nt = tile / (K / 64);
+  const int64_t nt = tile % (N / 32), kt = tile / (N / 32);  // kt-major: see layout note
   const int64_t n = nt * 32 + (lane & 31);
   const int64_t kb = kt * 64 + j * 16 + (lane >> 5) * 8;
   const W4Dq<T> dq(sz[(kb / gs) * N + n]);
@@ -190,15 +217,31 @@ struct Mfma<f16_tag> {
 
 constexpr int W4_KC = 128;  // K chunk (LDS row = 256 B = 16 x 16-B slots, XOR-swizzled by row&15)
 
-// MT: 32-token tiles per workgroup (BM = 32*MT); NTW: 32-column tiles per wave (BN = 128*NTW);
-// NG: scale groups per 128-deep chunk (1 for group >= 128, 2 for 64, 4 for 32)
-template <typename T, int MT, int NTW, int NG>
-__global__ void __launch_bounds__(256) w4a16_gemm_kernel(const GemmKParams p) {
+// MT : 32-token tiles per workgroup (BM = 32*MT)
+// NTW: 32-column tiles per wave      (BN = 128*NTW, 4 waves split N: weights stay wave-private)
+// NG : scale groups per 128-deep chunk (1 for group >= 128, 2 for 64, 4 for 32)
+// PC : K chunks staged per pass; PC*MT*8 KiB per LDS buffer (32 KiB when PC*MT = 4), 2 buffers.
+//
+// Pipeline per pass (PC chunks = 2*PC weight loads per n-tile per lane):
+//   top   : issue the NEXT pass's scale loads and A-tile loads (global -> registers)
+//   body  : for every half-chunk (one 16-B weight load = 4 MFMA k-steps):
+//             dequantise its 4 words -> 4 B fragments, re-issue that ring slot with the next pass's
+//             load (pinned by sched_barrier so hipcc keeps COUNTED vmcnt waits), then the MFMAs,
+//             A fragments coming from the swizzled LDS tile
+//   bottom: the A registers (older in the vmcnt queue than the re-issued weight loads, so a counted
+//           wait leaves a full pass of weight loads in flight) -> other LDS buffer, one barrier.
+template <typename T, int MT, int NTW, int NG, int PC, bool POST>
+__global__ void __launch_bounds__(256, (POST && PC * MT == 4 && MT < 4) ? 1 : 2) w4a16_gemm_kernel(const GemmKParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Mfma<T>::frag frag_t;
   constexpr int BM = 32 * MT;
-  constexpr int A_LD = MT * 2;            // 16-B slots staged per thread per chunk
-  constexpr int BUF_BYTES = BM * 256;
+  constexpr int A_LD = PC * MT * 2;  // 16-B slots staged per thread per pass
+  constexpr int CHUNK_BYTES = BM * 256;
+  constexpr int BUF_BYTES = PC * CHUNK_BYTES;
+  constexpr int HC = 2 * PC;  // half-chunks (16-B weight loads per lane) per pass
+  // POST: per-(chunk, group, row) activation sums X, fp32, after the two A buffers
+  constexpr int XS_FLOATS = PC * NG * BM;
+  float* xs_base = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -212,6 +255,7 @@ __global__ void __launch_bounds__(256) w4a16_gemm_kernel(const GemmKParams p) {
   const int64_t m0 = (int64_t)mb * BM;
   const int c0 = ks * p.chunks_per_split;
   const int c1 = min(p.n_chunks, c0 + p.chunks_per_split);
+  const int n_pass = (c1 - c0) / PC;  // host guarantees (c1 - c0) % PC == 0
 
   // this wave's column tiles (clamped: out-of-range tiles compute on the last valid tile, no store)
   const int64_t n_tiles = p.N / 32;
@@ -223,7 +267,6 @@ __global__ void __launch_bounds__(256) w4a16_gemm_kernel(const GemmKParams p) {
     nvalid[t] = g < n_tiles;
     ntile[t] = nvalid[t] ? g : n_tiles - 1;
   }
-  const int64_t ktiles = p.K / 64;
 
   f32x16 acc[NTW][MT];
 #pragma unroll
@@ -233,88 +276,159 @@ __global__ void __launch_bounds__(256) w4a16_gemm_kernel(const GemmKParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][m][r] = 0.f;
 
-  // ---- A staging: thread -> (row, slot) pairs, global 16-B loads, swizzled LDS writes ----
+  f32x16 tmp[POST ? NTW : 1][POST ? MT : 1];  // per-group partial sums (POST form only)
+  (void)tmp;
+
+  // ---- A staging: thread -> (chunk, row, slot), global 16-B loads, swizzled LDS writes ----
   const char* abase = reinterpret_cast<const char*>(p.a);
   u32x4 areg[A_LD];
-  auto a_load = [&](int c) {
+  auto a_load = [&](int cfirst) {  // chunks cfirst .. cfirst+PC-1
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       const int idx = tid + 256 * i;
-      const int row = idx >> 4, slot = idx & 15;
+      const int ch = idx / (BM * 16), rem = idx % (BM * 16);
+      const int row = rem >> 4, slot = rem & 15;
       const int64_t m = m0 + row;
       const int64_t mc = m < p.M ? m : p.M - 1;  // clamp (rows >= M are never stored)
-      areg[i] = *reinterpret_cast<const u32x4*>(abase + 2 * (mc * p.lda + (int64_t)c * W4_KC + slot * 8));
+      areg[i] = *reinterpret_cast<const u32x4*>(
+          abase + 2 * (mc * p.lda + (int64_t)(cfirst + ch) * W4_KC + slot * 8));
     }
   };
   auto a_store = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
       const int idx = tid + 256 * i;
-      const int row = idx >> 4, slot = idx & 15;
-      *reinterpret_cast<u32x4*>(smem + buf * BUF_BYTES + row * 256 + ((slot ^ (row & 15)) << 4)) = areg[i];
-    }
-  };
-
-  // ---- weight / scale loads for one chunk ----
-  u32x4 wreg[NTW][2];
-  uint32_t szreg[NTW][NG];
-  auto w_load = [&](int c) {
-#pragma unroll
-    for (int t = 0; t < NTW; ++t) {
-      const uint32_t* wp = p.wq + ((ntile[t] * ktiles + (int64_t)c * 2) * 64 + lane) * 4;
-      wreg[t][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp));
-      wreg[t][1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + 256));
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        const int64_t grp = ((int64_t)c * W4_KC + g * (W4_KC / NG)) >> p.gs_shift;
-        szreg[t][g] = p.sz[grp * p.N + ntile[t] * 32 + (lane & 31)];
+      const int ch = idx / (BM * 16), rem = idx % (BM * 16);
+      const int row = rem >> 4, slot = rem & 15;
+      *reinterpret_cast<u32x4*>(smem + buf * BUF_BYTES + ch * CHUNK_BYTES + row * 256 +
+                                ((slot ^ (row & 15)) << 4)) = areg[i];
+      if constexpr (POST) {
+        // the 16 slots of one (chunk, row) sit in 16 consecutive lanes (one DPP row): reduce the
+        // 8-element partial sums over the 16/NG lanes of each scale group
+        const u32x4 a = areg[i];
+        float sum = lo_f32<T>(a.x) + hi_f32<T>(a.x) + lo_f32<T>(a.y) + hi_f32<T>(a.y) +
+                    lo_f32<T>(a.z) + hi_f32<T>(a.z) + lo_f32<T>(a.w) + hi_f32<T>(a.w);
+        sum = group_sum<16 / NG>(sum);
+        if ((slot & (16 / NG - 1)) == 0)
+          xs_base[buf * XS_FLOATS + (ch * NG + slot / (16 / NG)) * BM + row] = sum;
       }
     }
   };
 
-  if (c0 < c1) {
+  // ---- weight ring (one 16-B load per half-chunk per n-tile) and per-chunk scale/zero words ----
+  u32x4 wreg[NTW][HC];
+  uint32_t szcur[NTW][PC][NG], sznext[NTW][PC][NG];
+  auto w_issue = [&](int t, int h, int cfirst) {  // half-chunk h of the pass starting at cfirst
+    const uint32_t* wp = p.wq + ((((int64_t)cfirst * 2 + h) * n_tiles + ntile[t]) * 64 + lane) * 4;
+    wreg[t][h] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp));
+  };
+  auto sz_load = [&](uint32_t (&dst)[NTW][PC][NG], int cfirst) {
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int c = 0; c < PC; ++c)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int64_t grp = ((int64_t)(cfirst + c) * W4_KC + g * (W4_KC / NG)) >> p.gs_shift;
+          dst[t][c][g] = p.sz[grp * p.N + ntile[t] * 32 + (lane & 31)];
+        }
+  };
+
+  if (n_pass > 0) {
+    sz_load(szcur, c0);
     a_load(c0);
-    w_load(c0);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+      for (int h = 0; h < HC; ++h) w_issue(t, h, c0);
     a_store(0);
   }
   __syncthreads();
 
   const int mrow = lane & 31, kh = lane >> 5;
-  for (int c = c0; c < c1; ++c) {
-    const int buf = (c - c0) & 1;
-    // dequantise this chunk's weights into MFMA B fragments
-    frag_t bfrag[NTW][8];
+  for (int ps = 0; ps < n_pass; ++ps) {
+    const int buf = ps & 1;
+    const int cnext = c0 + min(ps + 1, n_pass - 1) * PC;  // clamped: last pass reloads itself
+    sz_load(sznext, cnext);
+    a_load(cnext);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < NTW; ++t) {
+    for (int h = 0; h < HC; ++h) {
+      const int cl = h >> 1;  // chunk within the pass
+      frag_t bfrag[NTW][4];
 #pragma unroll
-      for (int w8 = 0; w8 < 8; ++w8) {
-        const W4Dq<T> dq(szreg[t][w8 * NG / 8]);
-        uint32_t o[4];
-        const u32x4 wv = wreg[t][w8 >> 2];
-        const uint32_t word = (w8 & 3) == 0 ? wv.x : (w8 & 3) == 1 ? wv.y : (w8 & 3) == 2 ? wv.z : wv.w;
-        dq.word(word, o);
-        const u32x4 packed = {o[0], o[1], o[2], o[3]};
-        bfrag[t][w8] = __builtin_bit_cast(frag_t, packed);
+      for (int t = 0; t < NTW; ++t) {
+        const u32x4 wv = wreg[t][h];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int w8 = (h & 1) * 4 + j;  // word index inside the 128-deep chunk
+          uint32_t o[4];
+          const uint32_t word = j == 0 ? wv.x : j == 1 ? wv.y : j == 2 ? wv.z : wv.w;
+          if constexpr (POST) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = ((word >> (4 * i)) & 0x000F000Fu) | W4Magic<T>::bits;
+          } else {
+            const W4Dq<T> dq(szcur[t][cl][w8 * NG / 8]);
+            dq.word(word, o);
+          }
+          const u32x4 packed = {o[0], o[1], o[2], o[3]};
+          bfrag[t][j] = __builtin_bit_cast(frag_t, packed);
+        }
+        w_issue(t, h, cnext);  // ring slot is free: prefetch the same half-chunk of the next pass
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int w8 = (h & 1) * 4 + j;
+        const int slot = w8 * 2 + kh;
+        constexpr int WPG = 8 / NG;  // k-steps (words) per scale group
+        const bool g_first = (w8 % WPG) == 0, g_last = (w8 % WPG) == WPG - 1;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int row = m * 32 + mrow;
+          const u32x4 av = *reinterpret_cast<const u32x4*>(
+              smem + buf * BUF_BYTES + cl * CHUNK_BYTES + row * 256 + ((slot ^ (row & 15)) << 4));
+          const frag_t af = __builtin_bit_cast(frag_t, av);
+#pragma unroll
+          for (int t = 0; t < NTW; ++t) {
+            if constexpr (POST) {
+              if (g_first) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                tmp[t][m] = Mfma<T>::run(af, bfrag[t][j], z);
+              } else {
+                tmp[t][m] = Mfma<T>::run(af, bfrag[t][j], tmp[t][m]);
+              }
+              if (g_last) {
+                // acc += s * (tmp - (magic + z) * X[row]) for this lane's column
+                float sc, zm;
+                W4Magic<T>::decode(szcur[t][cl][w8 * NG / 8], sc, zm);
+                const float nzs = -zm * sc;
+                const float* xs = xs_base + buf * XS_FLOATS + (cl * NG + w8 * NG / 8) * BM + m * 32 + 4 * kh;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                  const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + 8 * q4);
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const int r = q4 * 4 + e;
+                    acc[t][m][r] = fmaf(sc, tmp[t][m][r], fmaf(nzs, xv[e], acc[t][m][r]));
+                  }
+                }
+              }
+            } else {
+              acc[t][m] = Mfma<T>::run(af, bfrag[t][j], acc[t][m]);
+            }
+          }
+        }
       }
     }
-    // prefetch the next chunk (clamped at the end: a redundant reload, keeps the loop branch-free)
-    const int cn = min(c + 1, c1 - 1);
-    w_load(cn);
-    a_load(cn);
-    // MFMAs: A fragments from LDS (conflict-free swizzled ds_read_b128), reused across NTW tiles
 #pragma unroll
-    for (int k8 = 0; k8 < 8; ++k8) {
+    for (int t = 0; t < NTW; ++t)
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int row = m * 32 + mrow;
-        const int slot = k8 * 2 + kh;
-        const u32x4 av = *reinterpret_cast<const u32x4*>(smem + buf * BUF_BYTES + row * 256 +
-                                                         ((slot ^ (row & 15)) << 4));
-        const frag_t af = __builtin_bit_cast(frag_t, av);
+      for (int c = 0; c < PC; ++c)
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) acc[t][m] = Mfma<T>::run(af, bfrag[t][k8], acc[t][m]);
-      }
-    }
+        for (int g = 0; g < NG; ++g) szcur[t][c][g] = sznext[t][c][g];
     a_store(buf ^ 1);
     __syncthreads();
   }
@@ -355,8 +469,22 @@ __global__ void __launch_bounds__(256) w4_splitk_reduce_kernel(const float* __re
   if (idx4 * 4 >= M * N) return;
   const int64_t m = (idx4 * 4) / N, n = (idx4 * 4) % N;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < split_k; ++k)
-    s += *reinterpret_cast<const f32x4*>(part + ((int64_t)k * M + m) * N + n);
+  const float* src = part + m * N + n;
+  const int64_t slab = M * N;
+  int k = 0;
+  for (; k + 8 <= split_k; k += 8) {  // 8 independent 16-B loads in flight per thread
+    f32x4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + (k + i) * slab);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+  }
+  for (; k + 2 <= split_k; k += 2) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + k * slab);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(src + (k + 1) * slab);
+    s += a + b;
+  }
+  if (k < split_k) s += *reinterpret_cast<const f32x4*>(src + k * slab);
   if (bias) {
     const u32x2 b = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(bias) + n);
     s.x += lo_f32<T>(b.x); s.y += hi_f32<T>(b.x);
@@ -370,7 +498,7 @@ __global__ void __launch_bounds__(256) w4_splitk_reduce_kernel(const float* __re
 
 // ------------------------------- host side ------------------------------------------
 struct GemmPlan {
-  int mt, ntw, ng, split_k, chunks_per_split, n_mblocks, n_nblocks;
+  int mt, ntw, ng, pc, post, split_k, chunks_per_split, n_mblocks, n_nblocks;
   size_t lds_bytes, part_bytes, aperm_bytes;
 };
 
@@ -389,7 +517,18 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
     return SLM_ERR_UNSUPPORTED;
   if (a->K % gs) return SLM_ERR_UNSUPPORTED;
   pl->ng = gs == 32 ? 4 : gs == 64 ? 2 : 1;
-  int mt = a->M <= 32 ? 1 : a->M <= 64 ? 2 : 4;
+  // Launch shape from tools/sweep_gemm.py on MI355X (profiles/r01_gemm_sweep.jsonl):
+  //  M <= 64 : one M tile (MT = 1/2), post-scaled dequant, ~256 workgroups (split-K fills the chip)
+  //  M  > 64 : BM = 128 when the N x M tiling alone gives >= 256 tiles or K is deep, else BM = 64;
+  //            ~512 workgroups (2 per CU), split-K <= 8
+  const int n_chunks = (int)(a->K / W4_KC);
+  int mt;
+  if (a->M <= 32) mt = 1;
+  else if (a->M <= 64) mt = 2;
+  else {
+    const int64_t tiles4 = ((a->M + 127) / 128) * ((a->N + 127) / 128);
+    mt = (tiles4 >= 256 || a->K >= 8192) ? 4 : 2;
+  }
   mt = w4_env_int("SLM_W4_MT", mt);
   if (mt != 1 && mt != 2 && mt != 4) mt = 4;
   int ntw = w4_env_int("SLM_W4_NTW", 1);
@@ -400,43 +539,75 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   const int bm = 32 * mt, bn = 128 * ntw;
   pl->n_mblocks = (int)((a->M + bm - 1) / bm);
   pl->n_nblocks = (int)((a->N + bn - 1) / bn);
-  const int n_chunks = (int)(a->K / W4_KC);
   const int64_t tiles = (int64_t)pl->n_mblocks * pl->n_nblocks;
+  // pass = PC chunks per LDS buffer (PC*MT <= 4); one chunk per pass measured best or equal
+  int pc = w4_env_int("SLM_W4_PC", 1);
+  if (pc != 1 && pc != 2 && pc != 4) pc = 1;
+  if (pc * mt > 4) pc = 4 / mt;
+  while (pc > 1 && n_chunks % pc) pc >>= 1;
+  const int n_units = n_chunks / pc;  // split-K granularity = whole passes
   int split_k = w4_env_int("SLM_W4_SPLITK", 0);
   if (split_k <= 0) {
-    // fill ~2 workgroups per CU, keep >= 4 chunks (512 of K) per split
-    int64_t want = (512 + tiles - 1) / (tiles > 0 ? tiles : 1);
-    const int64_t cap = n_chunks / 4 > 0 ? n_chunks / 4 : 1;
-    if (want > cap) want = cap;
+    const int64_t target = a->M <= 64 ? 256 : 512;
+    int64_t want = (target + tiles / 2) / (tiles > 0 ? tiles : 1);
     if (want < 1) want = 1;
+    if (want > 8) want = 8;
+    if (want > n_units) want = n_units;
     split_k = (int)want;
   }
-  if (split_k > n_chunks) split_k = n_chunks;
-  pl->chunks_per_split = (n_chunks + split_k - 1) / split_k;
-  pl->split_k = (n_chunks + pl->chunks_per_split - 1) / pl->chunks_per_split;
-  pl->lds_bytes = (size_t)2 * bm * 256;
+  if (split_k > n_units) split_k = n_units;
+  const int units_per_split = (n_units + split_k - 1) / split_k;
+  pl->pc = pc;
+  pl->chunks_per_split = units_per_split * pc;
+  pl->split_k = (n_units + units_per_split - 1) / units_per_split;
+  // small-M tiles use the post-scaled form (7 VALU per 8 weights instead of ~27)
+  pl->post = w4_env_int("SLM_W4_POST", mt <= 2 ? 1 : 0) != 0 && mt <= 2;
+  pl->lds_bytes = (size_t)2 * pc * bm * 256 + (pl->post ? (size_t)2 * pc * pl->ng * bm * sizeof(float) : 0);
   pl->part_bytes = pl->split_k > 1 ? (size_t)pl->split_k * a->M * a->N * sizeof(float) : 0;
   pl->aperm_bytes = a->perm ? (((size_t)a->M * a->K * 2 + 255) & ~(size_t)255) : 0;
   return SLM_OK;
 }
 
-template <typename T, int MT, int NTW>
+template <typename T, int MT, int NTW, int PC>
 static void launch_gemm_ng(const GemmKParams& kp, const GemmPlan& pl, hipStream_t st) {
   const dim3 grid((unsigned)((int64_t)pl.n_nblocks * pl.n_mblocks * pl.split_k)), blk(256);
-  switch (pl.ng) {
-    case 4: hipLaunchKernelGGL((w4a16_gemm_kernel<T, MT, NTW, 4>), grid, blk, pl.lds_bytes, st, kp); break;
-    case 2: hipLaunchKernelGGL((w4a16_gemm_kernel<T, MT, NTW, 2>), grid, blk, pl.lds_bytes, st, kp); break;
-    default: hipLaunchKernelGGL((w4a16_gemm_kernel<T, MT, NTW, 1>), grid, blk, pl.lds_bytes, st, kp); break;
+#define SLM_GEMM(NGG, POSTT)                                                                        \
+  hipLaunchKernelGGL((w4a16_gemm_kernel<T, MT, NTW, NGG, PC, POSTT>), grid, blk, pl.lds_bytes, st, kp)
+  if constexpr (MT <= 2) {
+    if (pl.post) {
+      switch (pl.ng) {
+        case 4: SLM_GEMM(4, true); break;
+        case 2: SLM_GEMM(2, true); break;
+        default: SLM_GEMM(1, true); break;
+      }
+      return;
+    }
   }
+  switch (pl.ng) {
+    case 4: SLM_GEMM(4, false); break;
+    case 2: SLM_GEMM(2, false); break;
+    default: SLM_GEMM(1, false); break;
+  }
+#undef SLM_GEMM
+}
+
+template <typename T, int MT, int NTW>
+static void launch_gemm_pc(const GemmKParams& kp, const GemmPlan& pl, hipStream_t st) {
+  constexpr int PCMAX = 4 / MT;
+  if (pl.pc == PCMAX) launch_gemm_ng<T, MT, NTW, PCMAX>(kp, pl, st);
+  else if constexpr (PCMAX >= 4) {
+    if (pl.pc == 2) launch_gemm_ng<T, MT, NTW, 2>(kp, pl, st);
+    else launch_gemm_ng<T, MT, NTW, 1>(kp, pl, st);
+  } else launch_gemm_ng<T, MT, NTW, 1>(kp, pl, st);
 }
 
 template <typename T>
 static void launch_gemm(const GemmKParams& kp, const GemmPlan& pl, hipStream_t st) {
-  if (pl.mt == 4) launch_gemm_ng<T, 4, 1>(kp, pl, st);
-  else if (pl.mt == 2 && pl.ntw == 2) launch_gemm_ng<T, 2, 2>(kp, pl, st);
-  else if (pl.mt == 2) launch_gemm_ng<T, 2, 1>(kp, pl, st);
-  else if (pl.ntw == 2) launch_gemm_ng<T, 1, 2>(kp, pl, st);
-  else launch_gemm_ng<T, 1, 1>(kp, pl, st);
+  if (pl.mt == 4) launch_gemm_pc<T, 4, 1>(kp, pl, st);
+  else if (pl.mt == 2 && pl.ntw == 2) launch_gemm_pc<T, 2, 2>(kp, pl, st);
+  else if (pl.mt == 2) launch_gemm_pc<T, 2, 1>(kp, pl, st);
+  else if (pl.ntw == 2) launch_gemm_pc<T, 1, 2>(kp, pl, st);
+  else launch_gemm_pc<T, 1, 1>(kp, pl, st);
 }
 
 }  // namespace slm
