@@ -65,6 +65,24 @@ def _rand_int4_linear(gen, K, N, group_size, fmt, dtype, device):
     return {"qweight": qweight, "qzeros": qzeros, "scales": scales}
 
 
+def _shard_cols(ck, fmt, col_ranges):
+    """Column-parallel shard of a checkpoint-format layer: concatenation of the given [n0, n1)
+    column ranges (all multiples of 8) -- how LOAD_FUSED_WEIGHT / LOAD_SHARDED_WEIGHT slice dim 1
+    (src/layers/linear/weight_utils.h:48-83, qkv_parallel_linear.cpp:20-60)."""
+    def cat(t, div):
+        return torch.cat([t[:, a // div:b // div] for a, b in col_ranges], dim=1).contiguous()
+    return {"qweight": cat(ck["qweight"], 8 if fmt == "awq" else 1), "qzeros": cat(ck["qzeros"], 8),
+            "scales": cat(ck["scales"], 1)}
+
+
+def _shard_rows(ck, fmt, k0, k1, group_size):
+    """Row-parallel shard [k0, k1) of K (multiples of the group size)."""
+    div = 1 if fmt == "awq" else 8
+    return {"qweight": ck["qweight"][k0 // div:k1 // div].contiguous(),
+            "qzeros": ck["qzeros"][k0 // group_size:k1 // group_size].contiguous(),
+            "scales": ck["scales"][k0 // group_size:k1 // group_size].contiguous()}
+
+
 class LlamaDecodeStep:
     def __init__(self, shape: LlamaShape, max_batch_tokens: int, n_blocks: int, block_size: int,
                  parallel_args: Optional[ParallelArgs] = None, quant_method: str = "awq",
@@ -79,7 +97,9 @@ class LlamaDecodeStep:
         self.n_kv_heads = max(shape.n_kv_heads // tp, 1)
         self.block_size = block_size
         D, H = shape.head_dim, shape.hidden
-        gen = torch.Generator(device=self.device).manual_seed(seed * 1000 + pa.rank)
+        # every rank draws the SAME full-size synthetic checkpoint (common seed) and keeps its
+        # tensor-parallel shard, so TP=N and TP=1 are the same model (tests compare them)
+        gen = torch.Generator(device=self.device).manual_seed(seed * 1000 + 17)
         qa = QuantArgs(quant_method=quant_method, bits=4, group_size=group_size,
                        zero_point=(quant_method == "awq"))
         inv_freq = 1.0 / (shape.rope_theta ** (torch.arange(0, D, 2, dtype=torch.float32,
@@ -88,19 +108,33 @@ class LlamaDecodeStep:
         handler = HipAttnHandler(sm_scale=D ** -0.5, rotary_dim=D, cos_sin=cos_sin, interleaved=False)
         self.attn = Attention(self.n_heads, self.n_kv_heads, D, handler)
         qkv_n = (self.n_heads + 2 * self.n_kv_heads) * D
+        r, nh, nkv = pa.rank, self.n_heads, self.n_kv_heads
+        kv_head0 = (r * shape.n_kv_heads) // tp  # first kv head of this rank (replicated if HKV < TP)
+        q_full, kv_full, inter = shape.n_heads * D, shape.n_kv_heads * D, shape.intermediate
         self.layers = []
         for _ in range(shape.n_layers):
             L = {}
             L["qkv"] = ColumnParallelQLinear(H, qkv_n * tp, False, qa, False, pa, dtype, self.device)
-            L["o"] = RowParallelQLinear(self.n_heads * D * tp, H, False, qa, True, pa, dtype, self.device)
-            L["gate_up"] = ColumnParallelQLinear(H, 2 * shape.intermediate, False, qa, False, pa, dtype,
-                                                 self.device)
-            L["down"] = RowParallelQLinear(shape.intermediate, H, False, qa, True, pa, dtype, self.device)
-            for name, (K, N) in {"qkv": (H, qkv_n), "o": (self.n_heads * D, H),
-                                 "gate_up": (H, 2 * shape.intermediate // tp),
-                                 "down": (shape.intermediate // tp, H)}.items():
-                L[name].load_state_dict(_rand_int4_linear(gen, K, N, group_size, quant_method, dtype,
-                                                          self.device))
+            L["o"] = RowParallelQLinear(q_full, H, False, qa, True, pa, dtype, self.device)
+            L["gate_up"] = ColumnParallelQLinear(H, 2 * inter, False, qa, False, pa, dtype, self.device)
+            L["down"] = RowParallelQLinear(inter, H, False, qa, True, pa, dtype, self.device)
+            full = _rand_int4_linear(gen, H, q_full + 2 * kv_full, group_size, quant_method, dtype, self.device)
+            shard = {
+                "qkv": _shard_cols(full, quant_method, [
+                    (r * nh * D, (r + 1) * nh * D),
+                    (q_full + kv_head0 * D, q_full + (kv_head0 + nkv) * D),
+                    (q_full + kv_full + kv_head0 * D, q_full + kv_full + (kv_head0 + nkv) * D)])}
+            full = _rand_int4_linear(gen, q_full, H, group_size, quant_method, dtype, self.device)
+            shard["o"] = _shard_rows(full, quant_method, r * nh * D, (r + 1) * nh * D, group_size)
+            full = _rand_int4_linear(gen, H, 2 * inter, group_size, quant_method, dtype, self.device)
+            shard["gate_up"] = _shard_cols(full, quant_method, [
+                (r * inter // tp, (r + 1) * inter // tp),
+                (inter + r * inter // tp, inter + (r + 1) * inter // tp)])
+            full = _rand_int4_linear(gen, inter, H, group_size, quant_method, dtype, self.device)
+            shard["down"] = _shard_rows(full, quant_method, r * inter // tp, (r + 1) * inter // tp, group_size)
+            del full
+            for name in ("qkv", "o", "gate_up", "down"):
+                L[name].load_state_dict(shard[name])
                 L[name].verify_loaded_weights()
                 L[name]._repack()
             L["in_norm"] = (1 + 0.05 * torch.randn(H, device=self.device, generator=gen)).to(dtype)
@@ -109,8 +143,12 @@ class LlamaDecodeStep:
             self.layers.append(L)
         self.final_norm = (1 + 0.05 * torch.randn(H, device=self.device, generator=gen)).to(dtype)
         # hidden-sharded embedding + all-gather (embedding.h:74-81); vocab-sharded lm_head, gathered
-        self.embed = (torch.randn(shape.vocab, H // tp, device=self.device, generator=gen) * 0.02).to(dtype)
-        self.lm_head = (torch.randn(H, shape.vocab // tp, device=self.device, generator=gen) * 0.02).to(dtype)
+        embed = (torch.randn(shape.vocab, H, device=self.device, generator=gen) * 0.02).to(dtype)
+        self.embed = embed[:, r * H // tp:(r + 1) * H // tp].contiguous()
+        lm_head = (torch.randn(H, shape.vocab, device=self.device, generator=gen) * 0.02).to(dtype)
+        self.lm_head = lm_head[:, r * shape.vocab // tp:(r + 1) * shape.vocab // tp].contiguous()
+        del embed, lm_head
+        self.kv_head0 = kv_head0
         T = max_batch_tokens
         e = lambda *s: torch.empty(*s, dtype=dtype, device=self.device)  # noqa: E731
         self.buf = dict(resid=e(T, H), normed=e(T, H), qkv=e(T, qkv_n), attn=e(T, self.n_heads, D),
@@ -124,9 +162,16 @@ class LlamaDecodeStep:
         'tile': one 256 MiB normal block tiled over every layer's cache (fast; random enough for
         timing -- no two layers alias, nothing fits a cache)."""
         blk = None
-        for L in self.layers:
-            for t in L["kv"].get_kv_cache():
-                if mode == "randn":
+        for li, L in enumerate(self.layers):
+            for ti, t in enumerate(L["kv"].get_kv_cache()):
+                if mode == "consistent":
+                    # same full-head history on every rank (tests): draw all heads, keep this shard
+                    g2 = torch.Generator(device=self.device).manual_seed(7919 * li + ti)
+                    full = torch.randn(t.size(0), self.shape.n_kv_heads, t.size(2), device=self.device,
+                                       dtype=self.dtype, generator=g2)
+                    h0 = self.kv_head0
+                    t.copy_(full[:, h0:h0 + self.n_kv_heads])
+                elif mode == "randn":
                     t.normal_(generator=gen)
                 else:
                     flat = t.view(-1)
@@ -145,8 +190,8 @@ class LlamaDecodeStep:
         need = max(need, 64 * n_tokens * max(2 * s.intermediate // self.pa.world_size, s.hidden) * 4)
         kernels.reserve_workspace(min(need, 4 << 30), self.device)
 
-    def forward(self, tokens: torch.Tensor, positions: torch.Tensor,
-                params: InputParameters) -> torch.Tensor:
+    def forward(self, tokens: torch.Tensor, positions: torch.Tensor, params: InputParameters,
+                return_logits: bool = False) -> torch.Tensor:
         """tokens/positions [T] int32 -> next-token ids [n_seqs] (greedy), last token per sequence."""
         s, b, pa = self.shape, self.buf, self.pa
         T = tokens.numel()
@@ -179,6 +224,8 @@ class LlamaDecodeStep:
         if pa.world_size > 1:
             from .model_parallel import gather_from_model_parallel_region
             logits = gather_from_model_parallel_region(logits, pa)
+        if return_logits:
+            return logits
         return torch.argmax(logits.float(), dim=-1).to(torch.int32)
 
 

@@ -77,7 +77,11 @@ class ProcessGroup:
             kw = {}
             if use_gpu:
                 kw["device_id"] = device
-            dist.init_process_group(backend="nccl" if use_gpu else "gloo",
+            # SLM_DIST_BACKEND=gloo lets several ranks share one GPU (tests on a 1-GPU box)
+            backend = os.environ.get("SLM_DIST_BACKEND", "nccl" if use_gpu else "gloo")
+            if backend != "nccl":
+                kw = {}
+            dist.init_process_group(backend=backend,
                                     rank=int(os.environ.get("RANK", "0")), world_size=world, **kw)
         return ProcessGroup()
 
