@@ -334,6 +334,29 @@ __global__ void __launch_bounds__(256, (POST && PC * MT == 4 && MT < 4) ? 1 : 2)
         }
   };
 
+  // dequantise (PRE) / unpack (POST) one 16-B weight vector into 4 MFMA B fragments
+  auto make_frags = [&](const u32x4 wv, const uint32_t (&szc)[NG], int half, frag_t (&out)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int w8 = half * 4 + j;  // word index inside the 128-deep chunk
+      uint32_t o[4];
+      const uint32_t word = j == 0 ? wv.x : j == 1 ? wv.y : j == 2 ? wv.z : wv.w;
+      if constexpr (POST) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = ((word >> (4 * i)) & 0x000F000Fu) | W4Magic<T>::bits;
+      } else {
+        const W4Dq<T> dq(szc[w8 * NG / 8]);
+        dq.word(word, o);
+      }
+      const u32x4 packed = {o[0], o[1], o[2], o[3]};
+      out[j] = __builtin_bit_cast(frag_t, packed);
+    }
+  };
+
+  // Software pipeline inside the wave: while the MFMAs of half-chunk h run (matrix pipe), the VALU
+  // dequantises half-chunk h+1 into the other fragment buffer; the ring slot of h+1 is then
+  // re-issued one pass ahead (pinned by sched_barrier so the vmcnt waits stay counted).
+  frag_t bfrag[2][NTW][4];
   if (n_pass > 0) {
     sz_load(szcur, c0);
     a_load(c0);
@@ -342,41 +365,28 @@ __global__ void __launch_bounds__(256, (POST && PC * MT == 4 && MT < 4) ? 1 : 2)
 #pragma unroll
       for (int h = 0; h < HC; ++h) w_issue(t, h, c0);
     a_store(0);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      make_frags(wreg[t][0], szcur[t][0], 0, bfrag[0][t]);
+      w_issue(t, 0, c0 + min(1, n_pass - 1) * PC);
+    }
   }
   __syncthreads();
 
   const int mrow = lane & 31, kh = lane >> 5;
   for (int ps = 0; ps < n_pass; ++ps) {
     const int buf = ps & 1;
-    const int cnext = c0 + min(ps + 1, n_pass - 1) * PC;  // clamped: last pass reloads itself
+    const int cnext = c0 + min(ps + 1, n_pass - 1) * PC;   // clamped: last pass reloads itself
+    const int cnext2 = c0 + min(ps + 2, n_pass - 1) * PC;
     sz_load(sznext, cnext);
     a_load(cnext);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int h = 0; h < HC; ++h) {
       const int cl = h >> 1;  // chunk within the pass
-      frag_t bfrag[NTW][4];
-#pragma unroll
-      for (int t = 0; t < NTW; ++t) {
-        const u32x4 wv = wreg[t][h];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int w8 = (h & 1) * 4 + j;  // word index inside the 128-deep chunk
-          uint32_t o[4];
-          const uint32_t word = j == 0 ? wv.x : j == 1 ? wv.y : j == 2 ? wv.z : wv.w;
-          if constexpr (POST) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = ((word >> (4 * i)) & 0x000F000Fu) | W4Magic<T>::bits;
-          } else {
-            const W4Dq<T> dq(szcur[t][cl][w8 * NG / 8]);
-            dq.word(word, o);
-          }
-          const u32x4 packed = {o[0], o[1], o[2], o[3]};
-          bfrag[t][j] = __builtin_bit_cast(frag_t, packed);
-        }
-        w_issue(t, h, cnext);  // ring slot is free: prefetch the same half-chunk of the next pass
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      const int cur = h & 1, nxt = cur ^ 1;
+      const int hf = (h + 1) % HC;          // following half-chunk (first of the next pass at the end)
+      const bool wrap = (h + 1) == HC;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int w8 = (h & 1) * 4 + j;
@@ -396,9 +406,9 @@ __global__ void __launch_bounds__(256, (POST && PC * MT == 4 && MT < 4) ? 1 : 2)
                 f32x16 z;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                tmp[t][m] = Mfma<T>::run(af, bfrag[t][j], z);
+                tmp[t][m] = Mfma<T>::run(af, bfrag[cur][t][j], z);
               } else {
-                tmp[t][m] = Mfma<T>::run(af, bfrag[t][j], tmp[t][m]);
+                tmp[t][m] = Mfma<T>::run(af, bfrag[cur][t][j], tmp[t][m]);
               }
               if (g_last) {
                 // acc += s * (tmp - (magic + z) * X[row]) for this lane's column
@@ -417,11 +427,33 @@ __global__ void __launch_bounds__(256, (POST && PC * MT == 4 && MT < 4) ? 1 : 2)
                 }
               }
             } else {
-              acc[t][m] = Mfma<T>::run(af, bfrag[t][j], acc[t][m]);
+              acc[t][m] = Mfma<T>::run(af, bfrag[cur][t][j], acc[t][m]);
             }
           }
         }
+        // one word of the following half-chunk per k-step, in the shadow of the MFMAs above
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          const u32x4 wv = wreg[t][hf];
+          const int w8n = (hf & 1) * 4 + j;
+          uint32_t o[4];
+          const uint32_t word = j == 0 ? wv.x : j == 1 ? wv.y : j == 2 ? wv.z : wv.w;
+          if constexpr (POST) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = ((word >> (4 * i)) & 0x000F000Fu) | W4Magic<T>::bits;
+          } else {
+            const uint32_t szw = wrap ? sznext[t][0][w8n * NG / 8] : szcur[t][hf >> 1][w8n * NG / 8];
+            const W4Dq<T> dq(szw);
+            dq.word(word, o);
+          }
+          const u32x4 packed = {o[0], o[1], o[2], o[3]};
+          bfrag[nxt][t][j] = __builtin_bit_cast(frag_t, packed);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) w_issue(t, hf, wrap ? cnext2 : cnext);  // slot hf is free again
+      __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int t = 0; t < NTW; ++t)
