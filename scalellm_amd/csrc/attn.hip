@@ -23,47 +23,9 @@
 //  * online softmax in base 2 (common/online_softmax.cuh:39-162 semantics), fp32 accumulate,
 //    exact conditional rescale (skipped when no running max moved in the wave).
 //  * split-KV partials (m, l, O) + combine kernel (math of attn_combine_kernel.cuh:14-21).
-#include "common.h"
+#include "attn_common.h"
 
 namespace slm {
-
-constexpr int ATTN_TBL_ENT = 2048;  // block-table entries staged per chunk (8 KiB LDS)
-constexpr float ATTN_M_INIT = -1.0e30f;
-constexpr float LOG2E = 1.4426950408889634f;
-
-struct AttnKParams {
-  void* out;
-  const void* q;
-  const void* kc;
-  const void* vc;
-  int64_t o_ts, o_hs, q_ts, q_hs, k_ss, k_hs, v_ss, v_hs;  // strides in elements
-  const int* q_cu;
-  const int* kv_cu;
-  const int* bt;
-  const int* bcu;
-  const float* alibi;
-  float* o_part;   // [n_tokens, n_heads, n_splits, head_dim]
-  float* ml_part;  // [n_tokens, n_heads, n_splits, 2]
-  int batch, n_tokens, n_heads, n_kv_heads, head_dim;
-  int block_shift, block_mask;
-  int group;      // q heads per kv head
-  int n_chunks;   // group / GC
-  int hpw_shift;  // log2(kv heads per wave-load)
-  int hgw_shift;  // log2(head groups per workgroup)
-  int nhgb;       // head-group blocks = n_kv_heads / (HPW * HGW)
-  int n_splits;
-  int window;
-  float scale_log2;  // (softcap > 0 ? softcap : sm_scale) * log2(e)
-  float pre_scale;   // sm_scale / softcap   (softcap > 0 only)
-  float softcap;
-};
-
-// tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e)); saturates correctly at +-inf, abs error ~1e-7
-// (the reference kernel uses tanh.approx: common/fast_math.h:30-60).
-__device__ __forceinline__ float fast_tanh(float x) {
-  const float t = fast_exp2(x * (2.0f * LOG2E));
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + t);
-}
 
 template <bool NT>
 __device__ __forceinline__ u32x4 ld16(const void* p) {
@@ -106,6 +68,7 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
     b = lo_b;
   }
   if (b >= p.batch) return;  // padding token past q_cu[batch]
+  if ((p.q_cu[b + 1] - p.q_cu[b]) * p.group >= p.split_rows) return;  // long-q sequence: tile kernel owns it
 
   const int q_start = p.q_cu[b];
   const int q_len = p.q_cu[b + 1] - q_start;
@@ -599,6 +562,31 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
     kp.softcap = 0.f; kp.pre_scale = 0.f; kp.scale_log2 = a->sm_scale * LOG2E;
   }
   kp.o_part = nullptr; kp.ml_part = nullptr;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // Many query rows per KV head (prefill, chunked prefill, speculative verify): MFMA tile kernel.
+  // max_q_len is the same scheduling contract as the reference's grid (tile_scheduler.cuh:23-27).
+  // A forced split count keeps the call on the token-major kernel.
+  kp.split_rows = 0x7fffffff;  // token-major kernel takes everything unless the tile kernel runs
+  if (a->max_q_len > 1 && a->num_splits <= 0 && env_int("SLM_ATTN_TILE", 1) != 0) {
+    hip_clear_error();
+    const int64_t max_rows = (int64_t)a->max_q_len * kp.group;
+    if (max_rows <= 32) {
+      // every sequence is short (speculative verify): one-wave tiles, K/V read once per sequence
+      kp.split_rows = 0;
+      rc = launch_attn_tile(kp, a->dtype, a->max_q_len, st);
+      if (rc != SLM_ERR_UNSUPPORTED) return rc;
+      kp.split_rows = 0x7fffffff;
+    } else {
+      // mixed batch: sequences with > 32 query rows per KV head go to the MFMA tile kernel
+      // (4-wave tiles), the short ones (decode / verify rows) stay on the token-major stream
+      // kernel; each kernel skips the other's sequences from the device-side lengths.
+      kp.split_rows = 33;
+      rc = launch_attn_tile(kp, a->dtype, a->max_q_len, st);
+      if (rc != SLM_OK && rc != SLM_ERR_UNSUPPORTED) return rc;
+      if (rc == SLM_ERR_UNSUPPORTED) kp.split_rows = 0x7fffffff;
+      else { pl.n_splits = 1; kp.n_splits = 1; }  // no combine pass over rows the tile kernel wrote
+    }
+  }
   if (pl.n_splits > 1) {
     const size_t need =
         (size_t)a->n_tokens * a->n_heads * pl.n_splits * (a->head_dim + 2) * sizeof(float);
@@ -607,7 +595,6 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
     kp.ml_part = kp.o_part + (size_t)a->n_tokens * a->n_heads * pl.n_splits * a->head_dim;
   }
   hip_clear_error();
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int64_t grid = (int64_t)a->n_tokens * pl.nhgb * pl.n_chunks * pl.n_splits;
   if (grid <= 0 || grid > 0x7fffffffLL) return SLM_ERR_INVALID_ARG;
   if (a->dtype == SLM_BF16)

@@ -1,0 +1,53 @@
+// attn_common.h -- parameter block and helpers shared by the attention kernels.
+#pragma once
+#include "common.h"
+
+namespace slm {
+
+constexpr int ATTN_TBL_ENT = 2048;  // block-table entries staged per chunk (8 KiB LDS)
+constexpr float ATTN_M_INIT = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct AttnKParams {
+  void* out;
+  const void* q;
+  const void* kc;
+  const void* vc;
+  int64_t o_ts, o_hs, q_ts, q_hs, k_ss, k_hs, v_ss, v_hs;  // strides in elements
+  const int* q_cu;
+  const int* kv_cu;
+  const int* bt;
+  const int* bcu;
+  const float* alibi;
+  float* o_part;   // [n_tokens, n_heads, n_splits, head_dim]
+  float* ml_part;  // [n_tokens, n_heads, n_splits, 2]
+  int batch, n_tokens, n_heads, n_kv_heads, head_dim;
+  int block_shift, block_mask;
+  int group;      // q heads per kv head
+  int n_chunks;   // group / GC
+  int hpw_shift;  // log2(kv heads per wave-load)
+  int hgw_shift;  // log2(head groups per workgroup)
+  int nhgb;       // head-group blocks = n_kv_heads / (HPW * HGW)
+  int n_splits;
+  int window;
+  float scale_log2;  // (softcap > 0 ? softcap : sm_scale) * log2(e)
+  float pre_scale;   // sm_scale / softcap   (softcap > 0 only)
+  float softcap;
+  // mixed batches: sequences whose q_len * group is below / at-or-above this row count are left to
+  // the other kernel (token-major kernel takes < split_rows, tile kernel takes >= split_rows)
+  int split_rows;
+};
+
+// tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e)); saturates correctly at +-inf, abs error ~1e-7
+// (the reference kernel uses tanh.approx: common/fast_math.h:30-60).
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float t = fast_exp2(x * (2.0f * LOG2E));
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + t);
+}
+
+// MFMA tile kernel (attn_tile.hip): prefill / chunked prefill / speculative verify.
+// Returns SLM_OK after launching, or SLM_ERR_UNSUPPORTED when the shape is not covered
+// (the caller then uses the token-major kernel).
+int launch_attn_tile(const AttnKParams& kp, int dtype, int max_q_len, hipStream_t st);
+
+}  // namespace slm

@@ -1,0 +1,250 @@
+// attn_tile.hip -- MFMA tile kernel for paged-KV attention with MANY query rows per KV head:
+// prefill, chunked prefill and speculative verify (q_len = k+1), where attention is a real dense
+// contraction (unlike q_len = 1 decode, which stays on the VALU stream kernel in attn.hip).
+// Same operator, same semantics (reference src/kernels/attention/attn_api.cpp:14-73; masks
+// common/mask.h:49-89; online softmax common/online_softmax.cuh:39-162).
+//
+// Work item: one workgroup = (sequence, kv head, tile of 32*NW query rows), a "query row" being a
+// (token, q-head-in-group) pair with the head fastest -- the GQA group shares every K/V byte
+// (the reference packs GQA into M the same way: sm80_kernel_mha.cuh:93-137).  Each wave owns 32
+// query rows and walks the KV range in tiles of 32 rows:
+//
+//   S^T[32 kv x 32 q] = K . Q^T     8 (D=128) x v_mfma_f32_32x32x16: A = K rows from LDS (XOR-swizzled,
+//                                   conflict-free ds_read_b128), B = Q rows, loaded once from global
+//                                   straight into fragment registers (8 consecutive dims per lane).
+//   The swapped product leaves every lane with 16 scores of ONE query row (C layout: col = q row):
+//   row max / sum are 16 register ops + one lane-half exchange -- no LDS, no 32-lane butterflies.
+//   P^T stays in registers: the C-fragment row order {4h+e, 8+4h+e} per k-step is used as the
+//   contraction order of P.V as well, so cvt_pk of the softmax outputs IS the MFMA B operand.
+//   O^T[D x 32 q] += V^T . P^T      (D/32 x 2) MFMAs; A = V^T read from a transposed LDS image
+//                                   (row stride 72 B: conflict-free ds_read_b64, two per fragment).
+//   O accumulators have col = q row, so the online-softmax rescale is one scalar per lane.
+//
+// K/V rows are gathered through the block table (slot = table[i >> log2 bs] + (i & (bs-1)),
+// bit-exact with sm80_kernel_mha.cuh:146-152) by all waves of the workgroup, 16 B per lane.
+#include "attn_common.h"
+
+namespace slm {
+
+template <typename T>
+struct TileMfma;
+template <>
+struct TileMfma<bf16_tag> {
+  typedef bf16x8_t frag;
+  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct TileMfma<f16_tag> {
+  typedef f16x8_t frag;
+  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+constexpr int TILE_KV = 32;
+constexpr int VT_STRIDE = 72;  // bytes per d-row of the transposed V image (32 kv * 2 B + 8 pad)
+
+template <typename T, int HD>
+__global__ void __launch_bounds__(256) attn_tile_kernel(const AttnKParams p, int tiles_per_seq) {
+  typedef typename TileMfma<T>::frag frag_t;
+  constexpr int KSTEPS = HD / 16;     // MFMA k-steps of the QK product
+  constexpr int DT = HD / 32;         // 32-row d-tiles of the output
+  constexpr int NSLOT = HD / 8;       // 16-B slots per K row
+  constexpr int K_BYTES = TILE_KV * HD * 2;
+  __shared__ __attribute__((aligned(16))) char k_lds[K_BYTES];
+  __shared__ __attribute__((aligned(16))) char vt_lds[HD * VT_STRIDE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nthreads = blockDim.x;
+  const int hh = lane >> 5;
+  const int l31 = lane & 31;
+
+  int bid = blockIdx.x;
+  const int tile = bid % tiles_per_seq;
+  bid /= tiles_per_seq;
+  const int kvh = bid % p.n_kv_heads;
+  const int b = bid / p.n_kv_heads;
+
+  const int q_start = p.q_cu[b];
+  const int q_len = p.q_cu[b + 1] - q_start;
+  const int kv_len = p.kv_cu[b + 1] - p.kv_cu[b];
+  const int G = p.group;
+  const int rows_total = q_len * G;
+  const int rows_per_wg = 32 * (nthreads >> 6);
+  const int row0 = tile * rows_per_wg;
+  if (row0 >= rows_total || kv_len <= 0) return;  // workgroup-uniform
+  if (rows_total < p.split_rows) return;          // short-q sequence: the token-major kernel owns it
+
+  // this lane's query row
+  const int jrow = row0 + wave * 32 + l31;
+  const bool jvalid = jrow < rows_total;
+  const int tq = jvalid ? jrow / G : (rows_total - 1) / G;  // token index inside the sequence
+  const int head = kvh * G + (jvalid ? jrow % G : 0);
+  const int diag = kv_len - q_len + tq;  // last visible kv index of this row (causal)
+
+  // Q fragments (B operand of S^T = K . Q^T): 8 consecutive dims per lane per k-step
+  frag_t qf[KSTEPS];
+  {
+    const char* qp = reinterpret_cast<const char*>(p.q) +
+                     2 * ((int64_t)(q_start + tq) * p.q_ts + (int64_t)head * p.q_hs + 8 * hh);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (jvalid) v = *reinterpret_cast<const u32x4*>(qp + 32 * s);
+      qf[s] = __builtin_bit_cast(frag_t, v);
+    }
+  }
+  const float slope2 = p.alibi ? p.alibi[head] * LOG2E : 0.f;
+
+  // KV range of the workgroup: causal upper bound of its last row, window lower bound of its first
+  const int last_row = min(row0 + rows_per_wg, rows_total) - 1;
+  const int wg_hi = min(kv_len, kv_len - q_len + last_row / G + 1);
+  int wg_lo = 0;
+  if (p.window >= 0) wg_lo = max(0, kv_len - q_len + row0 / G - p.window);
+  wg_lo = (wg_lo / TILE_KV) * TILE_KV;
+
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = ATTN_M_INIT, l_run = 0.f;
+
+  const int bcu0 = p.bcu[b];
+  const char* kbase = reinterpret_cast<const char*>(p.kc) + 2 * (int64_t)kvh * p.k_hs;
+  const char* vbase = reinterpret_cast<const char*>(p.vc) + 2 * (int64_t)kvh * p.v_hs;
+  const uint32_t k_sb = (uint32_t)(2 * p.k_ss), v_sb = (uint32_t)(2 * p.v_ss);
+
+  for (int kt0 = wg_lo; kt0 < wg_hi; kt0 += TILE_KV) {
+    __syncthreads();  // previous tile fully consumed
+    // ---- stage K (row-major, swizzled) and V (transposed) tiles: 16 B per lane per item ----
+    for (int idx = tid; idx < TILE_KV * NSLOT; idx += nthreads) {
+      const int r = idx / NSLOT, sl = idx % NSLOT;
+      const int row = min(kt0 + r, kv_len - 1);  // clamp: masked below, must stay in bounds
+      const int slot = p.bt[bcu0 + (row >> p.block_shift)] + (row & p.block_mask);
+      const u32x4 kx = *reinterpret_cast<const u32x4*>(kbase + (uint64_t)(uint32_t)slot * k_sb + 16 * sl);
+      const u32x4 vx = *reinterpret_cast<const u32x4*>(vbase + (uint64_t)(uint32_t)slot * v_sb + 16 * sl);
+      *reinterpret_cast<u32x4*>(k_lds + r * (HD * 2) + ((sl ^ (r & (NSLOT - 1))) << 4)) = kx;
+      // V^T image: vt[d][kv r], d = 8*sl + e
+      uint16_t* vt = reinterpret_cast<uint16_t*>(vt_lds);
+      const uint32_t w[4] = {vx.x, vx.y, vx.z, vx.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        vt[(8 * sl + 2 * e) * (VT_STRIDE / 2) + r] = (uint16_t)(w[e] & 0xffffu);
+        vt[(8 * sl + 2 * e + 1) * (VT_STRIDE / 2) + r] = (uint16_t)(w[e] >> 16);
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T = K . Q^T ----
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      const int sl = 2 * s + hh;
+      const u32x4 kv4 = *reinterpret_cast<const u32x4*>(k_lds + l31 * (HD * 2) +
+                                                        ((sl ^ (l31 & (NSLOT - 1))) << 4));
+      sacc = TileMfma<T>::run(__builtin_bit_cast(frag_t, kv4), qf[s], sacc);
+    }
+
+    // ---- scale, soft-cap, alibi, mask; online softmax for this lane's query row ----
+    float sv[16];
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kv_idx = kt0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      float a = sacc[r];
+      if (p.softcap > 0.f) a = fast_tanh(a * p.pre_scale);
+      a = a * p.scale_log2 + slope2 * (float)kv_idx;
+      bool vis = jvalid && kv_idx <= diag && kv_idx < kv_len;
+      if (p.window >= 0) vis = vis && (diag - kv_idx) <= p.window;
+      a = vis ? a : -INFINITY;
+      sv[r] = a;
+      mloc = fmaxf(mloc, a);
+    }
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float m_new = fmaxf(m_run, mloc);
+    const float alpha = fast_exp2(m_run - m_new);
+    m_run = m_new;
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sv[r] = fast_exp2(sv[r] - m_new);
+      lsum += sv[r];
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    l_run = l_run * alpha + lsum;
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+    }
+
+    // ---- O^T += V^T . P^T : P fragments straight from the softmax registers ----
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      u32x4 pb;
+      pb.x = pack2<T>(sv[8 * s2 + 0], sv[8 * s2 + 1]);
+      pb.y = pack2<T>(sv[8 * s2 + 2], sv[8 * s2 + 3]);
+      pb.z = pack2<T>(sv[8 * s2 + 4], sv[8 * s2 + 5]);
+      pb.w = pack2<T>(sv[8 * s2 + 6], sv[8 * s2 + 7]);
+      const frag_t pfrag = __builtin_bit_cast(frag_t, pb);
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        // A[i = d row][k]: kv = 16*s2 + 4*hh + e (e < 4), 16*s2 + 8 + 4*hh + (e - 4)
+        const char* vrow = vt_lds + (d * 32 + l31) * VT_STRIDE + (16 * s2 + 4 * hh) * 2;
+        const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow);
+        const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 16);
+        const u32x4 va = {v0.x, v0.y, v1.x, v1.y};
+        oacc[d] = TileMfma<T>::run(__builtin_bit_cast(frag_t, va), pfrag, oacc[d]);
+      }
+    }
+  }
+
+  // ---- epilogue: O^T[d][q] / l -> out[token][head][d]; 4 consecutive d per register quad ----
+  if (!jvalid) return;
+  const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+  char* op = reinterpret_cast<char*>(p.out) +
+             2 * ((int64_t)(q_start + tq) * p.o_ts + (int64_t)head * p.o_hs);
+#pragma unroll
+  for (int d = 0; d < DT; ++d) {
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int dd = d * 32 + 8 * q4 + 4 * hh;  // rows (r&3) + 8*(r>>2) + 4*hh, r = 4*q4 .. 4*q4+3
+      u32x2 o2;
+      o2.x = pack2<T>(oacc[d][4 * q4 + 0] * inv, oacc[d][4 * q4 + 1] * inv);
+      o2.y = pack2<T>(oacc[d][4 * q4 + 2] * inv, oacc[d][4 * q4 + 3] * inv);
+      *reinterpret_cast<u32x2*>(op + 2 * dd) = o2;
+    }
+  }
+}
+
+int launch_attn_tile(const AttnKParams& kp, int dtype, int max_q_len, hipStream_t st) {
+  if (kp.head_dim != 64 && kp.head_dim != 128) return SLM_ERR_UNSUPPORTED;
+  if (max_q_len < 2) return SLM_ERR_UNSUPPORTED;
+  const int64_t rows = (int64_t)max_q_len * kp.group;  // query rows per (sequence, kv head)
+  int nw = (int)((rows + 31) / 32);
+  if (nw > 4) nw = 4;
+  if (nw == 3) nw = 4;
+  const int64_t tiles_per_seq = (rows + 32 * nw - 1) / (32 * nw);
+  const int64_t grid = tiles_per_seq * kp.n_kv_heads * kp.batch;
+  if (grid <= 0 || grid > 0x7fffffffLL) return SLM_ERR_UNSUPPORTED;
+  const dim3 g((unsigned)grid), blk(64 * nw);
+#define SLM_TILE(TT, HDD) \
+  hipLaunchKernelGGL((attn_tile_kernel<TT, HDD>), g, blk, 0, st, kp, (int)tiles_per_seq)
+  if (dtype == SLM_BF16) {
+    if (kp.head_dim == 128) SLM_TILE(bf16_tag, 128); else SLM_TILE(bf16_tag, 64);
+  } else {
+    if (kp.head_dim == 128) SLM_TILE(f16_tag, 128); else SLM_TILE(f16_tag, 64);
+  }
+#undef SLM_TILE
+  return hip_check_launch();
+}
+
+}  // namespace slm
