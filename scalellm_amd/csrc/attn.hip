@@ -68,7 +68,10 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
     b = lo_b;
   }
   if (b >= p.batch) return;  // padding token past q_cu[batch]
-  if ((p.q_cu[b + 1] - p.q_cu[b]) * p.group >= p.split_rows) return;  // long-q sequence: tile kernel owns it
+  {
+    const int rows = (p.q_cu[b + 1] - p.q_cu[b]) * p.group;
+    if (rows < p.rows_lo || rows >= p.rows_hi) return;  // another launch owns this sequence
+  }
 
   const int q_start = p.q_cu[b];
   const int q_len = p.q_cu[b + 1] - q_start;
@@ -326,6 +329,17 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const AttnKParams p, 
   const int64_t item = (int64_t)blockIdx.x * 4 + wv;
   if (item >= (int64_t)p.n_tokens * p.n_heads) return;
   const int tok = (int)(item / p.n_heads), head = (int)(item % p.n_heads);
+  if (p.rows_hi != 0x7fffffff || p.rows_lo != 0) {
+    // mixed call: only the rows the token-major kernel produced are combined
+    int lo_b = 0, hi_b = p.batch;
+    while (lo_b < hi_b) {
+      const int mid = (lo_b + hi_b) >> 1;
+      if (p.q_cu[mid + 1] <= tok) lo_b = mid + 1; else hi_b = mid;
+    }
+    if (lo_b >= p.batch) return;
+    const int rows = (p.q_cu[lo_b + 1] - p.q_cu[lo_b]) * p.group;
+    if (rows < p.rows_lo || rows >= p.rows_hi) return;
+  }
   const float* ml = p.ml_part + item * p.n_splits * 2;
   float mreg[4], lreg[4];
   float M = ATTN_M_INIT;
@@ -566,26 +580,32 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
   // Many query rows per KV head (prefill, chunked prefill, speculative verify): MFMA tile kernel.
   // max_q_len is the same scheduling contract as the reference's grid (tile_scheduler.cuh:23-27).
   // A forced split count keeps the call on the token-major kernel.
-  kp.split_rows = 0x7fffffff;  // token-major kernel takes everything unless the tile kernel runs
-  if (a->max_q_len > 1 && a->num_splits <= 0 && env_int("SLM_ATTN_TILE", 1) != 0) {
+  // Sequence classes by query rows per KV head (rows = q_len * group), decided on the DEVICE from
+  // q_cu_lens, so one call handles mixed prefill / verify / decode batches (BASELINE config 5):
+  //   rows <= group (q_len = 1)   token-major stream kernel (attn_token_kernel)
+  //   group < rows <= 32          MFMA tile kernel, one-wave tiles   (speculative verify)
+  //   rows > 32                   MFMA tile kernel, 2/4-wave tiles   (prefill, chunked prefill)
+  // max_q_len is the same scheduling contract as the reference's grid (tile_scheduler.cuh:23-27).
+  // A forced split count or an unsupported head_dim keeps everything on the token-major kernel.
+  kp.rows_lo = 0;
+  kp.rows_hi = 0x7fffffff;
+  if (a->max_q_len > 1 && a->num_splits <= 0 && attn_tile_supported(kp.head_dim) &&
+      env_int("SLM_ATTN_TILE", 1) != 0) {
     hip_clear_error();
     const int64_t max_rows = (int64_t)a->max_q_len * kp.group;
-    if (max_rows <= 32) {
-      // every sequence is short (speculative verify): one-wave tiles, K/V read once per sequence
-      kp.split_rows = 0;
-      rc = launch_attn_tile(kp, a->dtype, a->max_q_len, st);
-      if (rc != SLM_ERR_UNSUPPORTED) return rc;
-      kp.split_rows = 0x7fffffff;
-    } else {
-      // mixed batch: sequences with > 32 query rows per KV head go to the MFMA tile kernel
-      // (4-wave tiles), the short ones (decode / verify rows) stay on the token-major stream
-      // kernel; each kernel skips the other's sequences from the device-side lengths.
-      kp.split_rows = 33;
-      rc = launch_attn_tile(kp, a->dtype, a->max_q_len, st);
-      if (rc != SLM_OK && rc != SLM_ERR_UNSUPPORTED) return rc;
-      if (rc == SLM_ERR_UNSUPPORTED) kp.split_rows = 0x7fffffff;
-      else { pl.n_splits = 1; kp.n_splits = 1; }  // no combine pass over rows the tile kernel wrote
+    AttnKParams tk = kp;
+    tk.rows_lo = kp.group + 1;
+    tk.rows_hi = 33;
+    rc = launch_attn_tile(tk, a->dtype, max_rows < 32 ? max_rows : 32, st);
+    if (rc != SLM_OK) return rc;
+    if (max_rows > 32) {
+      tk.rows_lo = 33;
+      tk.rows_hi = 0x7fffffff;
+      rc = launch_attn_tile(tk, a->dtype, max_rows, st);
+      if (rc != SLM_OK) return rc;
     }
+    // the token-major kernel (and its split-KV combine pass) keeps the q_len = 1 sequences
+    kp.rows_hi = kp.group + 1;
   }
   if (pl.n_splits > 1) {
     const size_t need =

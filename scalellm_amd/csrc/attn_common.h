@@ -33,9 +33,9 @@ struct AttnKParams {
   float scale_log2;  // (softcap > 0 ? softcap : sm_scale) * log2(e)
   float pre_scale;   // sm_scale / softcap   (softcap > 0 only)
   float softcap;
-  // mixed batches: sequences whose q_len * group is below / at-or-above this row count are left to
-  // the other kernel (token-major kernel takes < split_rows, tile kernel takes >= split_rows)
-  int split_rows;
+  // mixed batches: a launch only processes sequences with rows_lo <= q_len * group < rows_hi
+  // (device-side lengths); the other classes belong to the other launches of the same call
+  int rows_lo, rows_hi;
 };
 
 // tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e)); saturates correctly at +-inf, abs error ~1e-7
@@ -48,6 +48,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // MFMA tile kernel (attn_tile.hip): prefill / chunked prefill / speculative verify.
 // Returns SLM_OK after launching, or SLM_ERR_UNSUPPORTED when the shape is not covered
 // (the caller then uses the token-major kernel).
-int launch_attn_tile(const AttnKParams& kp, int dtype, int max_q_len, hipStream_t st);
+bool attn_tile_supported(int head_dim);
+int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t max_rows, hipStream_t st);
 
 }  // namespace slm

@@ -46,8 +46,10 @@ struct TileMfma<f16_tag> {
 constexpr int TILE_KV = 32;
 constexpr int VT_STRIDE = 72;  // bytes per d-row of the transposed V image (32 kv * 2 B + 8 pad)
 
-template <typename T, int HD>
-__global__ void __launch_bounds__(256) attn_tile_kernel(const AttnKParams p, int tiles_per_seq) {
+// NW: waves per workgroup (compile-time so the staging registers are statically indexed).
+// PF: prefetch the next K/V tile into registers while the current one is consumed.
+template <typename T, int HD, int NW, bool PF>
+__global__ void __launch_bounds__(64 * NW) attn_tile_kernel(const AttnKParams p, int tiles_per_seq) {
   typedef typename TileMfma<T>::frag frag_t;
   constexpr int KSTEPS = HD / 16;     // MFMA k-steps of the QK product
   constexpr int DT = HD / 32;         // 32-row d-tiles of the output
@@ -59,7 +61,8 @@ __global__ void __launch_bounds__(256) attn_tile_kernel(const AttnKParams p, int
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nthreads = blockDim.x;
+  constexpr int nthreads = 64 * NW;
+  constexpr int ITEMS = TILE_KV * (HD / 8) / nthreads;  // 16-B staging items per thread per tile
   const int hh = lane >> 5;
   const int l31 = lane & 31;
 
@@ -77,7 +80,7 @@ __global__ void __launch_bounds__(256) attn_tile_kernel(const AttnKParams p, int
   const int rows_per_wg = 32 * (nthreads >> 6);
   const int row0 = tile * rows_per_wg;
   if (row0 >= rows_total || kv_len <= 0) return;  // workgroup-uniform
-  if (rows_total < p.split_rows) return;          // short-q sequence: the token-major kernel owns it
+  if (rows_total < p.rows_lo || rows_total >= p.rows_hi) return;  // another launch owns this sequence
 
   // this lane's query row
   const int jrow = row0 + wave * 32 + l31;
@@ -119,26 +122,52 @@ __global__ void __launch_bounds__(256) attn_tile_kernel(const AttnKParams p, int
   const char* vbase = reinterpret_cast<const char*>(p.vc) + 2 * (int64_t)kvh * p.v_hs;
   const uint32_t k_sb = (uint32_t)(2 * p.k_ss), v_sb = (uint32_t)(2 * p.v_ss);
 
-  for (int kt0 = wg_lo; kt0 < wg_hi; kt0 += TILE_KV) {
-    __syncthreads();  // previous tile fully consumed
-    // ---- stage K (row-major, swizzled) and V (transposed) tiles: 16 B per lane per item ----
-    for (int idx = tid; idx < TILE_KV * NSLOT; idx += nthreads) {
+  u32x4 kreg[ITEMS], vreg[ITEMS];
+  auto tile_load = [&](int kt0) {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int idx = tid + nthreads * i;
       const int r = idx / NSLOT, sl = idx % NSLOT;
       const int row = min(kt0 + r, kv_len - 1);  // clamp: masked below, must stay in bounds
       const int slot = p.bt[bcu0 + (row >> p.block_shift)] + (row & p.block_mask);
-      const u32x4 kx = *reinterpret_cast<const u32x4*>(kbase + (uint64_t)(uint32_t)slot * k_sb + 16 * sl);
-      const u32x4 vx = *reinterpret_cast<const u32x4*>(vbase + (uint64_t)(uint32_t)slot * v_sb + 16 * sl);
-      *reinterpret_cast<u32x4*>(k_lds + r * (HD * 2) + ((sl ^ (r & (NSLOT - 1))) << 4)) = kx;
+      kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (uint64_t)(uint32_t)slot * k_sb + 16 * sl);
+      vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (uint64_t)(uint32_t)slot * v_sb + 16 * sl);
+    }
+  };
+  auto tile_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int idx = tid + nthreads * i;
+      const int r = idx / NSLOT, sl = idx % NSLOT;
+      *reinterpret_cast<u32x4*>(k_lds + r * (HD * 2) + ((sl ^ (r & (NSLOT - 1))) << 4)) = kreg[i];
       // V^T image: vt[d][kv r], d = 8*sl + e
       uint16_t* vt = reinterpret_cast<uint16_t*>(vt_lds);
-      const uint32_t w[4] = {vx.x, vx.y, vx.z, vx.w};
+      const uint32_t w[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         vt[(8 * sl + 2 * e) * (VT_STRIDE / 2) + r] = (uint16_t)(w[e] & 0xffffu);
         vt[(8 * sl + 2 * e + 1) * (VT_STRIDE / 2) + r] = (uint16_t)(w[e] >> 16);
       }
     }
+  };
+
+  if constexpr (PF) {
+    if (wg_lo < wg_hi) {
+      tile_load(wg_lo);
+      tile_store();
+    }
     __syncthreads();
+  }
+  for (int kt0 = wg_lo; kt0 < wg_hi; kt0 += TILE_KV) {
+    if constexpr (PF) {
+      // next tile's rows travel HBM -> registers while this tile is consumed from LDS
+      tile_load(min(kt0 + TILE_KV, wg_hi - 1));
+    } else {
+      __syncthreads();  // previous tile fully consumed
+      tile_load(kt0);
+      tile_store();
+      __syncthreads();
+    }
 
     // ---- S^T = K . Q^T ----
     f32x16 sacc;
@@ -205,6 +234,11 @@ __global__ void __launch_bounds__(256) attn_tile_kernel(const AttnKParams p, int
         oacc[d] = TileMfma<T>::run(__builtin_bit_cast(frag_t, va), pfrag, oacc[d]);
       }
     }
+    if constexpr (PF) {
+      __syncthreads();  // every wave is done reading this tile
+      tile_store();
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: O^T[d][q] / l -> out[token][head][d]; 4 consecutive d per register quad ----
@@ -225,10 +259,12 @@ __global__ void __launch_bounds__(256) attn_tile_kernel(const AttnKParams p, int
   }
 }
 
-int launch_attn_tile(const AttnKParams& kp, int dtype, int max_q_len, hipStream_t st) {
-  if (kp.head_dim != 64 && kp.head_dim != 128) return SLM_ERR_UNSUPPORTED;
-  if (max_q_len < 2) return SLM_ERR_UNSUPPORTED;
-  const int64_t rows = (int64_t)max_q_len * kp.group;  // query rows per (sequence, kv head)
+bool attn_tile_supported(int head_dim) { return head_dim == 64 || head_dim == 128; }
+
+// rows = largest q_len * group this launch has to cover (query rows per (sequence, kv head))
+int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t rows, hipStream_t st) {
+  if (!attn_tile_supported(kp.head_dim)) return SLM_ERR_UNSUPPORTED;
+  if (rows < 1) return SLM_ERR_UNSUPPORTED;
   int nw = (int)((rows + 31) / 32);
   if (nw > 4) nw = 4;
   if (nw == 3) nw = 4;
@@ -236,13 +272,23 @@ int launch_attn_tile(const AttnKParams& kp, int dtype, int max_q_len, hipStream_
   const int64_t grid = tiles_per_seq * kp.n_kv_heads * kp.batch;
   if (grid <= 0 || grid > 0x7fffffffLL) return SLM_ERR_UNSUPPORTED;
   const dim3 g((unsigned)grid), blk(64 * nw);
-#define SLM_TILE(TT, HDD) \
-  hipLaunchKernelGGL((attn_tile_kernel<TT, HDD>), g, blk, 0, st, kp, (int)tiles_per_seq)
+  const char* pfe = getenv("SLM_ATTN_TILE_PF");
+  const bool pf = !(pfe && pfe[0] == '0');
+#define SLM_TILE(TT, HDD, NWW)                                                                    \
+  do {                                                                                            \
+    if (pf) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
+    else hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, false>), g, blk, 0, st, kp, (int)tiles_per_seq); \
+  } while (0)
+#define SLM_TILE_NW(TT, HDD)                                                                      \
+  do {                                                                                            \
+    if (nw == 1) SLM_TILE(TT, HDD, 1); else if (nw == 2) SLM_TILE(TT, HDD, 2); else SLM_TILE(TT, HDD, 4); \
+  } while (0)
   if (dtype == SLM_BF16) {
-    if (kp.head_dim == 128) SLM_TILE(bf16_tag, 128); else SLM_TILE(bf16_tag, 64);
+    if (kp.head_dim == 128) SLM_TILE_NW(bf16_tag, 128); else SLM_TILE_NW(bf16_tag, 64);
   } else {
-    if (kp.head_dim == 128) SLM_TILE(f16_tag, 128); else SLM_TILE(f16_tag, 64);
+    if (kp.head_dim == 128) SLM_TILE_NW(f16_tag, 128); else SLM_TILE_NW(f16_tag, 64);
   }
+#undef SLM_TILE_NW
 #undef SLM_TILE
   return hip_check_launch();
 }
