@@ -27,6 +27,13 @@
 
 namespace slm {
 
+// P.V as packed dot products over row pairs (P rounded to T) instead of fp32 FMAs: ~45 % fewer
+// VALU issue slots in the P.V part of the loop (profiles/README.md)
+#ifndef SLM_ATTN_PV_DOT2
+#define SLM_ATTN_PV_DOT2 1
+#endif
+constexpr bool PV_DOT2 = SLM_ATTN_PV_DOT2 != 0;
+
 template <bool NT>
 __device__ __forceinline__ u32x4 ld16(const void* p) {
   if constexpr (NT)
@@ -35,7 +42,10 @@ __device__ __forceinline__ u32x4 ld16(const void* p) {
     return *reinterpret_cast<const u32x4*>(p);
 }
 
-template <typename T, int LPR, int GC, int U, bool NT, bool SC>
+// FX: the rare score transforms (logits soft-cap and/or alibi) are compiled in; the FX = false fast
+// path folds the softmax scale into one fma per score, like the reference's exp2(x*s - max*s)
+// (common/online_softmax.cuh:39-162).
+template <typename T, int LPR, int GC, int U, bool NT, bool FX>
 __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* tbl = reinterpret_cast<int*>(smem);
@@ -181,55 +191,106 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
       float s[U][GC];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int row = wrow0 + (it0 + u) * RPI + rsub;
-        const bool valid = row < c_hi;
         const u32x4 kk = kr[u];
 #pragma unroll
         for (int h = 0; h < GC; ++h) {
           float a = dot2<T>(kk.x, qv[h][0], 0.f);
           a = dot2<T>(kk.y, qv[h][1], a);
           a = dot2<T>(kk.z, qv[h][2], a);
-          a = dot2<T>(kk.w, qv[h][3], a);
-          a = group_sum<LPR>(a);
-          if constexpr (SC) a = fast_tanh(a * p.pre_scale);  // logits soft-cap (template: no cost when off)
-          a = a * p.scale_log2 + slope2[h] * (float)row;
-          s[u][h] = valid ? a : -INFINITY;
+          s[u][h] = dot2<T>(kk.w, qv[h][3], a);
         }
         kr[u] = ld16<NT>(kbase + (uint64_t)(uint32_t)slot_n[u] * k_sb);
         __builtin_amdgcn_sched_barrier(0);  // pin: next-batch K load issues right here
       }
+      // 16-lane all-reduce of the U*GC partial sums, STEP-major: the U*GC independent chains are
+      // interleaved so the VALU-write -> DPP-read wait states are filled with useful work
+      group_sum_many<LPR, U * GC>(&s[0][0]);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int row = wrow0 + (it0 + u) * RPI + rsub;
+        const bool valid = row < c_hi;
+#pragma unroll
+        for (int h = 0; h < GC; ++h) {
+          float a = s[u][h];
+          if constexpr (FX) {
+            if (p.softcap > 0.f) a = fast_tanh(a * p.pre_scale);
+            a = a * p.scale_log2 + slope2[h] * (float)row;
+          }
+          s[u][h] = valid ? a : -INFINITY;
+        }
+      }
+      // one running-max update per batch of U rows (m is kept in score units when !FX)
+      float negm[GC];
 #pragma unroll
       for (int h = 0; h < GC; ++h) {
         float mn = m[h];
 #pragma unroll
         for (int u = 0; u < U; ++u) mn = fmaxf(mn, s[u][h]);
-        const float alpha = fast_exp2(m[h] - mn);
+        const float alpha = FX ? fast_exp2(m[h] - mn) : fast_exp2((m[h] - mn) * p.scale_log2);
+        negm[h] = FX ? -mn : -mn * p.scale_log2;
         m[h] = mn;
         l[h] *= alpha;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[h][j] *= alpha;
       }
+      float pr[U][GC];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const u32x4 vv = vr[u];
-        float vf[8];
-        vf[0] = lo_f32<T>(vv.x); vf[1] = hi_f32<T>(vv.x);
-        vf[2] = lo_f32<T>(vv.y); vf[3] = hi_f32<T>(vv.y);
-        vf[4] = lo_f32<T>(vv.z); vf[5] = hi_f32<T>(vv.z);
-        vf[6] = lo_f32<T>(vv.w); vf[7] = hi_f32<T>(vv.w);
+      for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int h = 0; h < GC; ++h) {
-          const float pr = fast_exp2(s[u][h] - m[h]);
-          l[h] += pr;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[h][j] = fmaf(pr, vf[j], o[h][j]);
+          pr[u][h] = FX ? fast_exp2(s[u][h] + negm[h]) : fast_exp2(fmaf(s[u][h], p.scale_log2, negm[h]));
+          l[h] += pr[u][h];
         }
-        vr[u] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u] * v_sb);
-        __builtin_amdgcn_sched_barrier(0);  // pin: next-batch V load issues right here
+      if constexpr (PV_DOT2 && (U % 2 == 0)) {
+        // P.V over row PAIRS with v_dot2c: V words of two rows are byte-permuted into
+        // (row a, row b) pairs per dim, P is rounded to T (as every MFMA flash-attention does)
+#pragma unroll
+        for (int u = 0; u < U; u += 2) {
+          const u32x4 va = vr[u], vb = vr[u + 1];
+          uint32_t pp[GC];
+#pragma unroll
+          for (int h = 0; h < GC; ++h) pp[h] = pack2<T>(pr[u][h], pr[u + 1][h]);
+          const uint32_t wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t lo = __builtin_amdgcn_perm(wb[j], wa[j], 0x05040100u);
+            const uint32_t hi = __builtin_amdgcn_perm(wb[j], wa[j], 0x07060302u);
+#pragma unroll
+            for (int h = 0; h < GC; ++h) {
+              o[h][2 * j] = dot2<T>(lo, pp[h], o[h][2 * j]);
+              o[h][2 * j + 1] = dot2<T>(hi, pp[h], o[h][2 * j + 1]);
+            }
+          }
+          vr[u] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u] * v_sb);
+          vr[u + 1] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u + 1] * v_sb);
+          __builtin_amdgcn_sched_barrier(0);  // pin: next-batch V loads issue right here
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const u32x4 vv = vr[u];
+          float vf[8];
+          vf[0] = lo_f32<T>(vv.x); vf[1] = hi_f32<T>(vv.x);
+          vf[2] = lo_f32<T>(vv.y); vf[3] = hi_f32<T>(vv.y);
+          vf[4] = lo_f32<T>(vv.z); vf[5] = hi_f32<T>(vv.z);
+          vf[6] = lo_f32<T>(vv.w); vf[7] = hi_f32<T>(vv.w);
+#pragma unroll
+          for (int h = 0; h < GC; ++h) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[h][j] = fmaf(pr[u][h], vf[j], o[h][j]);
+          }
+          vr[u] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u] * v_sb);
+          __builtin_amdgcn_sched_barrier(0);  // pin: next-batch V load issues right here
+        }
       }
       asm volatile("" ::: "memory");
     }
     c_lo = c_hi;
+  }
+
+  if constexpr (!FX) {  // running max was kept in raw score units: convert to log2 units for the merges
+#pragma unroll
+    for (int h = 0; h < GC; ++h) m[h] *= p.scale_log2;
   }
 
   // ---- merge the row-phase lane groups of this wave (same kv head, different rows) ----
@@ -481,8 +542,8 @@ static void launch_token_kernel(const AttnKParams& kp, const AttnPlan& pl, int64
   const dim3 g((unsigned)grid), blk(pl.nw * 64);
 #define SLM_LAUNCH(UU, NTT, SCC)                                                                \
   hipLaunchKernelGGL((attn_token_kernel<T, LPR, GC, UU, NTT, SCC>), g, blk, pl.lds_bytes, st, kp)
-  if (kp.softcap > 0.f) {
-    SLM_LAUNCH(2, false, true);  // soft-cap models (Gemma-2 class): one tuned shape
+  if (kp.softcap > 0.f || kp.alibi != nullptr) {
+    SLM_LAUNCH(2, false, true);  // soft-cap / alibi models: one tuned shape
   } else if (pl.u == 2) {
     if (pl.nt) SLM_LAUNCH(2, true, false); else SLM_LAUNCH(2, false, false);
   } else {

@@ -100,6 +100,28 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// all-reduce N independent values across aligned groups of W lanes, one DPP step at a time over
+// all N values (keeps N independent dependency chains adjacent in program order)
+template <int W, int N>
+__device__ __forceinline__ void group_sum_many(float* v) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_f32<DPP_QUAD_XOR1>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_f32<DPP_QUAD_XOR2>(v[i]);
+  if constexpr (W >= 8) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_f32<DPP_ROW_HALF_MIRROR>(v[i]);
+  }
+  if constexpr (W >= 16) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_f32<DPP_ROW_MIRROR>(v[i]);
+  }
+  if constexpr (W >= 32) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += __shfl_xor(v[i], 16, 64);
+  }
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // hipGetLastError() is per-thread sticky state shared with every other HIP user in the process
