@@ -161,6 +161,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kv-fill", default="randn", choices=["tile", "randn"])
+    ap.add_argument("--simulate-tp", type=int, default=0, help="tuning aid: run rank 0's shard of a "
+                    "TP=N step on one GPU with the collectives stubbed (flagged in the output)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -176,6 +178,10 @@ def main():
     torch.cuda.set_device(device)
     pg = ProcessGroup.create_from_env(device)
     pa = ParallelArgs(rank=pg.rank, world_size=pg.world_size, process_group=pg)
+    if args.simulate_tp > 1:
+        from scalellm_amd.model_parallel import LocalShardProcessGroup
+        pa = ParallelArgs(rank=0, world_size=args.simulate_tp,
+                          process_group=LocalShardProcessGroup(args.simulate_tp))
 
     shape = LlamaShape.llama3_8b()
     reduced = False
@@ -274,6 +280,7 @@ def main():
                        "global_batch": bs, "seq_len": L,
                        "parallelism": f"tp{world}" if world > 1 else "single-gpu",
                        "hip_graph": graph is not None, "reduced_model": reduced,
+                       "simulated_tp_rank0_only": args.simulate_tp if args.simulate_tp > 1 else None,
                        "kv_cache_gib_per_gpu": round(2 * n_blocks * B * model.n_kv_heads * shape.head_dim
                                                      * 2 * shape.n_layers / 2 ** 30, 1),
                        "init_s": round(t_init, 1)},

@@ -582,8 +582,12 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   if (split_k <= 0) {
     const int64_t target = a->M <= 64 ? 256 : 512;
     int64_t want = (target + tiles / 2) / (tiles > 0 ? tiles : 1);
-    if (want < 1) want = 1;
+    // M > 64: keep >= 8 chunks (1024 of K) per split -- short K (row-parallel TP shards) does not
+    // amortise the fp32 partial round trip
+    const int64_t cap = a->M <= 64 ? 8 : (n_chunks / 8 > 0 ? n_chunks / 8 : 1);
+    if (want > cap) want = cap;
     if (want > 8) want = 8;
+    if (want < 1) want = 1;
     if (want > n_units) want = n_units;
     split_k = (int)want;
   }
@@ -593,7 +597,7 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   pl->chunks_per_split = units_per_split * pc;
   pl->split_k = (n_units + units_per_split - 1) / units_per_split;
   // small-M tiles use the post-scaled form (7 VALU per 8 weights instead of ~27)
-  pl->post = w4_env_int("SLM_W4_POST", mt <= 2 ? 1 : 0) != 0 && mt <= 2;
+  pl->post = w4_env_int("SLM_W4_POST", a->M <= 64 ? 1 : 0) != 0 && mt <= 2;
   pl->lds_bytes = (size_t)2 * pc * bm * 256 + (pl->post ? (size_t)2 * pc * pl->ng * bm * sizeof(float) : 0);
   pl->part_bytes = pl->split_k > 1 ? (size_t)pl->split_k * a->M * a->N * sizeof(float) : 0;
   pl->aperm_bytes = a->perm ? (((size_t)a->M * a->K * 2 + 255) & ~(size_t)255) : 0;

@@ -86,6 +86,35 @@ class ProcessGroup:
         return ProcessGroup()
 
 
+class LocalShardProcessGroup(ProcessGroup):
+    """Tuning aid (bench.py --simulate-tp N): behaves like rank 0 of an N-way group on ONE GPU with
+    the collectives replaced by local stand-ins of the same output shape (all-reduce = no-op,
+    all-gather = N copies).  The per-rank COMPUTE is exactly that of a real TP=N run; numbers taken
+    this way are flagged as simulated and never reported as multi-GPU results."""
+
+    def __init__(self, world_size: int):
+        self._group = None
+        self._initialised = False
+        self.rank = 0
+        self.world_size = world_size
+
+    def allreduce(self, tensor):
+        return
+
+    def allgather(self, tensor, outputs):
+        for o in outputs:
+            o.copy_(tensor)
+
+    def allgather_into(self, tensor, output):
+        output.view(self.world_size, -1).copy_(tensor.reshape(1, -1).expand(self.world_size, -1))
+
+    def alltoall(self, tensor, output):
+        output.copy_(tensor)
+
+    def barrier(self):
+        return
+
+
 @dataclass
 class ParallelArgs:
     rank: int = 0

@@ -16,7 +16,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scalellm_amd import kernels  # noqa: E402
 from scalellm_amd.decode import _rand_int4_linear  # noqa: E402
 
-SHAPES = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "down": (14336, 4096)}
+SHAPES = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "down": (14336, 4096),
+          # per-rank shards of the same layer under TP=8 / TP=4 / TP=2 (column: N/tp, row: K/tp)
+          "qkv_tp8": (4096, 768), "o_tp8": (512, 4096), "gate_up_tp8": (4096, 3584), "down_tp8": (1792, 4096),
+          "qkv_tp4": (4096, 1536), "o_tp4": (1024, 4096), "gate_up_tp4": (4096, 7168), "down_tp4": (3584, 4096),
+          "qkv_tp2": (4096, 3072), "o_tp2": (2048, 4096), "gate_up_tp2": (4096, 14336), "down_tp2": (7168, 4096)}
 
 
 def main():
