@@ -51,37 +51,57 @@ def attn_algo_bytes(bs, kv_len, n_heads, n_kv_heads, head_dim, block, q_len=1, e
 
 
 def measure_attention_kernel(model, tokens, positions, params, n_launch):
-    """Average duration of the paged-attention launch (dominant kernel), HIP events on the
-    stream the kernel is launched on (torch's current stream), one launch per layer cache."""
+    """Average duration of the paged-attention launch (dominant kernel): HIP events on the stream
+    the kernels run on, bracketing a hipGraph of `n_launch` back-to-back launches (one per layer
+    cache, so no launch re-reads a cache the previous one touched).  Graph replay keeps the host
+    out of the interval: python/ctypes enqueue time (~20 us per call) would otherwise inflate it."""
     T = tokens.numel()
     q = torch.randn(T, model.n_heads, model.shape.head_dim, device=model.device, dtype=model.dtype)
     out = torch.empty_like(q)
+
+    def launches():
+        for i in range(n_launch):
+            kv = model.layers[i % len(model.layers)]["kv"]
+            model.attn.handler.batch_decode(q, kv, params, -1, out)
+
+    launches()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        launches()
+    g.replay()
+    torch.cuda.synchronize()
     times = []
-    for i in range(n_launch + 4):
-        kv = model.layers[i % len(model.layers)]["kv"]
+    for _ in range(5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        model.attn.handler.batch_decode(q, kv, params, -1, out)
+        g.replay()
         e1.record()
         e1.synchronize()
-        if i >= 4:
-            times.append(e0.elapsed_time(e1) * 1e3)  # us
+        times.append(e0.elapsed_time(e1) * 1e3 / n_launch)  # us per launch
     times.sort()
     return sum(times) / len(times), times[len(times) // 2]
 
 
 def measure_gemm(model, T):
-    """int4 GEMM TFLOP/s of the largest layer GEMM (gate_up) at M = batch tokens, HIP events."""
+    """int4 GEMM TFLOP/s of the largest layer GEMM (gate_up) at M = batch tokens (hipGraph of 20
+    launches between HIP events)."""
     L = model.layers[0]["gate_up"]
     x = torch.randn(T, L._packed.K, device=model.device, dtype=model.dtype)
     out = torch.empty(T, L._packed.N, device=model.device, dtype=model.dtype)
+    n = 20
     for _ in range(3):
         kernels.gptq_gemm(x, L._packed, out)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            kernels.gptq_gemm(x, L._packed, out)
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 20
     e0.record()
-    for _ in range(n):
-        kernels.gptq_gemm(x, L._packed, out)
+    g.replay()
     e1.record()
     e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / n
@@ -259,7 +279,7 @@ def main():
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
                     algorithmic_bytes_per_launch=nbytes, avg_launch_us=round(avg_us, 2),
-                    median_launch_us=round(med_us, 2), launches=32)
+                    median_launch_us=round(med_us, 2), launches="5 x 32 (hipGraph replay)")
     gemm = measure_gemm(model, bs)
 
     out = None

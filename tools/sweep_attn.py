@@ -36,10 +36,12 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--out", default="gpurun_out/sweep_attn.jsonl")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--heads", default="32,8", help="n_heads,n_kv_heads (e.g. 4,1 = a TP=8 shard)")
     args = ap.parse_args()
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     dev = "cuda"
-    H, HKV, D, B, L = 32, 8, 128, args.block, args.seqlen
+    H, HKV = (int(x) for x in args.heads.split(','))
+    D, B, L = 128, args.block, args.seqlen
     fout = open(args.out, "a")
     for bs in [int(x) for x in args.bs.split(",")]:
         g = torch.Generator(device=dev).manual_seed(bs)
