@@ -73,6 +73,9 @@ def set_kv_cache(slot_ids, keys: np.ndarray, values: np.ndarray, key_cache: np.n
     s = _i32(slot_ids)
     assert keys.flags.c_contiguous and values.flags.c_contiguous
     assert key_cache.flags.c_contiguous and value_cache.flags.c_contiguous
+    assert keys.dtype == key_cache.dtype == values.dtype == value_cache.dtype, "dtype mismatch"
+    assert keys.shape[1:] == key_cache.shape[1:] and values.shape[1:] == value_cache.shape[1:]
+    assert len(s) == 0 or (0 <= s.min() and s.max() < key_cache.shape[0]), "slot id out of range"
     row_bytes = int(np.prod(keys.shape[1:])) * keys.itemsize
     lib().oracle_set_kv_cache(_p(s, _i32p), C.c_int64(len(s)), C.c_void_p(keys.ctypes.data),
                               C.c_void_p(values.ctypes.data), C.c_int64(row_bytes),
