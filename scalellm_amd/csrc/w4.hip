@@ -25,76 +25,9 @@
 //    per 128-deep K chunk through XOR-swizzled LDS (conflict-free ds_read_b128); weights go
 //    HBM -> registers -> dequant -> MFMA B operand; fp32 accumulate; optional split-K with fp32
 //    partials + reduce (bias added after the reduction, as qlinear_awq_marlin_impl.cpp:357-363).
-#include "common.h"
+#include "w4_common.h"
 
 namespace slm {
-
-// ------------------------------------------------------------------------------------------
-// unpack helpers (shared by the GEMM and the debug dequant kernel: one code path to test)
-// ------------------------------------------------------------------------------------------
-template <typename T>
-struct W4Dq;
-
-template <>
-struct W4Dq<bf16_tag> {
-  float s, c;
-  __device__ __forceinline__ explicit W4Dq(uint32_t sz) {
-    s = __builtin_bit_cast(float, sz << 16);
-    const float zm = __builtin_bit_cast(float, sz & 0xffff0000u);  // 128 + zero, exact
-    c = -zm * s;                                                    // <= 16 significant bits: exact
-  }
-  // 8 nibbles -> 4 packed bf16 pairs, element order e = 0..7
-  __device__ __forceinline__ void word(uint32_t w, uint32_t (&out)[4]) const {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t t = ((w >> (4 * i)) & 0x000F000Fu) | 0x43004300u;  // (128+q_lo, 128+q_hi)
-      const float lo = __builtin_bit_cast(float, t << 16);
-      const float hi = __builtin_bit_cast(float, t & 0xffff0000u);
-      out[i] = pack2<bf16_tag>(fmaf(lo, s, c), fmaf(hi, s, c));  // (q - z) * s exact, then RN
-    }
-  }
-};
-
-template <>
-struct W4Dq<f16_tag> {
-  f16x2_t s2, nzm2;
-  __device__ __forceinline__ explicit W4Dq(uint32_t sz) {
-    const f16x2_t v = __builtin_bit_cast(f16x2_t, sz);
-    s2 = f16x2_t{v[0], v[0]};
-    nzm2 = f16x2_t{-v[1], -v[1]};  // -(1024 + zero)
-  }
-  __device__ __forceinline__ void word(uint32_t w, uint32_t (&out)[4]) const {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t t = ((w >> (4 * i)) & 0x000F000Fu) | 0x64006400u;  // (1024+q_lo, 1024+q_hi)
-      const f16x2_t d = __builtin_bit_cast(f16x2_t, t) + nzm2;          // q - z, exact
-      out[i] = __builtin_bit_cast(uint32_t, d * s2);                    // RN
-    }
-  }
-};
-
-// POST-scaled form (small-M kernels): the MFMA consumes the raw magic-number values (magic + q,
-// exact in T) -- unpack is 7 VALU per 8 weights instead of ~27 -- and the affine part is applied to
-// the per-group partial sums:  sum_k x_k s (q_k - z) = s * ( sum_k x_k (magic+q_k) - (magic+z) sum_k x_k ).
-template <typename T>
-struct W4Magic;
-template <>
-struct W4Magic<bf16_tag> {
-  static constexpr uint32_t bits = 0x43004300u;
-  static __device__ __forceinline__ void decode(uint32_t sz, float& s, float& zm) {
-    s = __builtin_bit_cast(float, sz << 16);
-    zm = __builtin_bit_cast(float, sz & 0xffff0000u);
-  }
-};
-template <>
-struct W4Magic<f16_tag> {
-  static constexpr uint32_t bits = 0x64006400u;
-  static __device__ __forceinline__ void decode(uint32_t sz, float& s, float& zm) {
-    const f16x2_t v = __builtin_bit_cast(f16x2_t, sz);
-    s = (float)v[0];
-    zm = (float)v[1];
-  }
-};
 
 __device__ __forceinline__ int awq_pos(int col_in_word) {  // [0,2,4,6,1,3,5,7] interleave
   return (col_in_word >> 1) + 4 * (col_in_word & 1);
@@ -183,39 +116,7 @@ __global__ void __launch_bounds__(256) w4_permute_cols_kernel(const uint16_t* __
 // ------------------------------------------------------------------------------------------
 // GEMM
 // ------------------------------------------------------------------------------------------
-struct GemmKParams {
-  const void* a;
-  const uint32_t* wq;
-  const uint32_t* sz;
-  const void* bias;
-  void* c;
-  float* part;  // [split_k][M][N] fp32 (split_k > 1)
-  int64_t M, K, N, lda, ldc;
-  int gs_shift;      // log2(group_size) (group_size >= 128 handled via k >> gs_shift too)
-  int n_chunks;      // K / 128
-  int split_k;
-  int chunks_per_split;
-  int n_mblocks, n_nblocks;
-};
-
-template <typename T>
-struct Mfma;
-template <>
-struct Mfma<bf16_tag> {
-  typedef bf16x8_t frag;
-  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <>
-struct Mfma<f16_tag> {
-  typedef f16x8_t frag;
-  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-  }
-};
-
-constexpr int W4_KC = 128;  // K chunk (LDS row = 256 B = 16 x 16-B slots, XOR-swizzled by row&15)
+// W4_KC = 128: K chunk (LDS row = 256 B = 16 x 16-B slots, XOR-swizzled by row&15)
 
 // MT : 32-token tiles per workgroup (BM = 32*MT)
 // NTW: 32-column tiles per wave      (BN = 128*NTW, 4 waves split N: weights stay wave-private)
@@ -557,15 +458,17 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   int mt;
   if (a->M <= 32) mt = 1;
   else if (a->M <= 64) mt = 2;
-  else {
+  else if (a->M <= 128) {
     const int64_t tiles4 = ((a->M + 127) / 128) * ((a->N + 127) / 128);
     mt = (tiles4 >= 256 || a->K >= 8192) ? 4 : 2;
+  } else {
+    mt = 8;  // wave-specialised 256 x 128 kernel (w4_ws.hip)
   }
   mt = w4_env_int("SLM_W4_MT", mt);
-  if (mt != 1 && mt != 2 && mt != 4) mt = 4;
+  if (mt != 1 && mt != 2 && mt != 4 && mt != 8) mt = 4;  // 8 = wave-specialised kernel (w4_ws.hip)
   int ntw = w4_env_int("SLM_W4_NTW", 1);
   if (ntw != 1 && ntw != 2) ntw = 1;
-  if (mt == 4) ntw = 1;
+  if (mt >= 4) ntw = 1;
   pl->mt = mt;
   pl->ntw = ntw;
   const int bm = 32 * mt, bn = 128 * ntw;
@@ -575,12 +478,12 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   // pass = PC chunks per LDS buffer (PC*MT <= 4); one chunk per pass measured best or equal
   int pc = w4_env_int("SLM_W4_PC", 1);
   if (pc != 1 && pc != 2 && pc != 4) pc = 1;
-  if (pc * mt > 4) pc = 4 / mt;
+  if (pc * mt > 4) pc = mt >= 4 ? 1 : 4 / mt;
   while (pc > 1 && n_chunks % pc) pc >>= 1;
   const int n_units = n_chunks / pc;  // split-K granularity = whole passes
   int split_k = w4_env_int("SLM_W4_SPLITK", 0);
   if (split_k <= 0) {
-    const int64_t target = a->M <= 64 ? 256 : 512;
+    const int64_t target = (a->M <= 64 || mt == 8) ? 256 : 512;
     int64_t want = (target + tiles / 2) / (tiles > 0 ? tiles : 1);
     // M > 64: keep >= 8 chunks (1024 of K) per split -- short K (row-parallel TP shards) does not
     // amortise the fp32 partial round trip
@@ -748,7 +651,9 @@ SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream) {
   kp.n_chunks = (int)(a->K / W4_KC);
   kp.split_k = pl.split_k; kp.chunks_per_split = pl.chunks_per_split;
   kp.n_mblocks = pl.n_mblocks; kp.n_nblocks = pl.n_nblocks;
-  if (a->dtype == SLM_BF16) launch_gemm<bf16_tag>(kp, pl, st);
+  if (pl.mt == 8)
+    launch_gemm_ws(kp, a->dtype, pl.ng, pl.n_nblocks * pl.n_mblocks * pl.split_k, st);
+  else if (a->dtype == SLM_BF16) launch_gemm<bf16_tag>(kp, pl, st);
   else launch_gemm<f16_tag>(kp, pl, st);
   rc = hip_check_launch();
   if (rc != SLM_OK) return rc;

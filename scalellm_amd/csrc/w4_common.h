@@ -1,0 +1,113 @@
+// w4_common.h -- shared pieces of the int4-weight GEMM kernels (w4.hip, w4_ws.hip): the dequant
+// helpers (one code path for the GEMMs and the debug dequant kernel), MFMA wrappers, kernel params.
+#pragma once
+#include "common.h"
+
+namespace slm {
+
+// ------------------------------------------------------------------------------------------
+// unpack helpers (shared by the GEMM and the debug dequant kernel: one code path to test)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+struct W4Dq;
+
+template <>
+struct W4Dq<bf16_tag> {
+  float s, c;
+  __device__ __forceinline__ explicit W4Dq(uint32_t sz) {
+    s = __builtin_bit_cast(float, sz << 16);
+    const float zm = __builtin_bit_cast(float, sz & 0xffff0000u);  // 128 + zero, exact
+    c = -zm * s;                                                    // <= 16 significant bits: exact
+  }
+  // 8 nibbles -> 4 packed bf16 pairs, element order e = 0..7
+  __device__ __forceinline__ void word(uint32_t w, uint32_t (&out)[4]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t t = ((w >> (4 * i)) & 0x000F000Fu) | 0x43004300u;  // (128+q_lo, 128+q_hi)
+      const float lo = __builtin_bit_cast(float, t << 16);
+      const float hi = __builtin_bit_cast(float, t & 0xffff0000u);
+      out[i] = pack2<bf16_tag>(fmaf(lo, s, c), fmaf(hi, s, c));  // (q - z) * s exact, then RN
+    }
+  }
+};
+
+template <>
+struct W4Dq<f16_tag> {
+  f16x2_t s2, nzm2;
+  __device__ __forceinline__ explicit W4Dq(uint32_t sz) {
+    const f16x2_t v = __builtin_bit_cast(f16x2_t, sz);
+    s2 = f16x2_t{v[0], v[0]};
+    nzm2 = f16x2_t{-v[1], -v[1]};  // -(1024 + zero)
+  }
+  __device__ __forceinline__ void word(uint32_t w, uint32_t (&out)[4]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t t = ((w >> (4 * i)) & 0x000F000Fu) | 0x64006400u;  // (1024+q_lo, 1024+q_hi)
+      const f16x2_t d = __builtin_bit_cast(f16x2_t, t) + nzm2;          // q - z, exact
+      out[i] = __builtin_bit_cast(uint32_t, d * s2);                    // RN
+    }
+  }
+};
+
+// POST-scaled form (small-M kernels): the MFMA consumes the raw magic-number values (magic + q,
+// exact in T) -- unpack is 7 VALU per 8 weights instead of ~27 -- and the affine part is applied to
+// the per-group partial sums:  sum_k x_k s (q_k - z) = s * ( sum_k x_k (magic+q_k) - (magic+z) sum_k x_k ).
+template <typename T>
+struct W4Magic;
+template <>
+struct W4Magic<bf16_tag> {
+  static constexpr uint32_t bits = 0x43004300u;
+  static __device__ __forceinline__ void decode(uint32_t sz, float& s, float& zm) {
+    s = __builtin_bit_cast(float, sz << 16);
+    zm = __builtin_bit_cast(float, sz & 0xffff0000u);
+  }
+};
+template <>
+struct W4Magic<f16_tag> {
+  static constexpr uint32_t bits = 0x64006400u;
+  static __device__ __forceinline__ void decode(uint32_t sz, float& s, float& zm) {
+    const f16x2_t v = __builtin_bit_cast(f16x2_t, sz);
+    s = (float)v[0];
+    zm = (float)v[1];
+  }
+};
+
+struct GemmKParams {
+  const void* a;
+  const uint32_t* wq;
+  const uint32_t* sz;
+  const void* bias;
+  void* c;
+  float* part;  // [split_k][M][N] fp32 (split_k > 1)
+  int64_t M, K, N, lda, ldc;
+  int gs_shift;      // log2(group_size) (group_size >= 128 handled via k >> gs_shift too)
+  int n_chunks;      // K / 128
+  int split_k;
+  int chunks_per_split;
+  int n_mblocks, n_nblocks;
+};
+
+template <typename T>
+struct Mfma;
+template <>
+struct Mfma<bf16_tag> {
+  typedef bf16x8_t frag;
+  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Mfma<f16_tag> {
+  typedef f16x8_t frag;
+  static __device__ __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+constexpr int W4_KC = 128;  // K granularity of the plan (split-K units, LDS chunk of the small-M kernels)
+
+// warp-specialised large-M kernel (w4_ws.hip): BM = 256, BN = 128, 512 threads
+void launch_gemm_ws(const GemmKParams& kp, int dtype, int ng, int n_blocks, hipStream_t st);
+constexpr size_t W4_WS_LDS_BYTES = 3 * (256 * 128 + 16 * 1024) + 2 * 4 * (1024 + 512);
+
+}  // namespace slm

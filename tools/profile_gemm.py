@@ -19,7 +19,10 @@ def main():
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(0)
     kernels.reserve_workspace(1 << 30)
+    only = os.environ.get("SHAPES", "")
     for name, (K, N) in SHAPES.items():
+        if only and name not in only.split(","):
+            continue
         ck = _rand_int4_linear(g, K, N, 128, "awq", torch.bfloat16, dev)
         packed = kernels.awq_repack(ck["qweight"], ck["qzeros"], ck["scales"], 128)
         for M in ms:
