@@ -462,10 +462,18 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
     const int64_t tiles4 = ((a->M + 127) / 128) * ((a->N + 127) / 128);
     mt = (tiles4 >= 256 || a->K >= 8192) ? 4 : 2;
   } else {
-    mt = 8;  // wave-specialised 256 x 128 kernel (w4_ws.hip)
+    // M > 128: the wave-specialised 256 x 128 kernel (w4_ws.hip) when its tiles alone keep about
+    // half of the 256 CUs busy (measured: 0.89-1.06 PFLOP/s vs 0.74-0.86 for the single-role
+    // kernel on gate_up/down at M = 256..2048); narrow layers stay on the 128 x 128 kernel, whose
+    // 2 workgroups per CU need less split-K.  Its A addressing uses 32-bit offsets.
+    const int64_t tiles8 = ((a->M + 255) / 256) * ((a->N + 127) / 128);
+    const bool a_fits = ((a->M - 1) * a->lda + a->K) * 2 < ((int64_t)1 << 31);
+    const int64_t tiles4 = ((a->M + 127) / 128) * ((a->N + 127) / 128);
+    mt = (tiles8 >= 112 && a_fits) ? 8 : ((tiles4 >= 256 || a->K >= 8192) ? 4 : 2);
   }
   mt = w4_env_int("SLM_W4_MT", mt);
   if (mt != 1 && mt != 2 && mt != 4 && mt != 8) mt = 4;  // 8 = wave-specialised kernel (w4_ws.hip)
+  if (mt == 8 && ((a->M - 1) * a->lda + a->K) * 2 >= ((int64_t)1 << 31)) mt = 4;
   int ntw = w4_env_int("SLM_W4_NTW", 1);
   if (ntw != 1 && ntw != 2) ntw = 1;
   if (mt >= 4) ntw = 1;

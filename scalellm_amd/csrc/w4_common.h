@@ -19,15 +19,17 @@ struct W4Dq<bf16_tag> {
     const float zm = __builtin_bit_cast(float, sz & 0xffff0000u);  // 128 + zero, exact
     c = -zm * s;                                                    // <= 16 significant bits: exact
   }
+  // nibble pair i (elements 2i, 2i+1) -> packed bf16 pair
+  __device__ __forceinline__ uint32_t pair(uint32_t w, int i) const {
+    const uint32_t t = ((w >> (4 * i)) & 0x000F000Fu) | 0x43004300u;  // (128+q_lo, 128+q_hi)
+    const float lo = __builtin_bit_cast(float, t << 16);
+    const float hi = __builtin_bit_cast(float, t & 0xffff0000u);
+    return pack2<bf16_tag>(fmaf(lo, s, c), fmaf(hi, s, c));  // (q - z) * s exact, then RN
+  }
   // 8 nibbles -> 4 packed bf16 pairs, element order e = 0..7
   __device__ __forceinline__ void word(uint32_t w, uint32_t (&out)[4]) const {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t t = ((w >> (4 * i)) & 0x000F000Fu) | 0x43004300u;  // (128+q_lo, 128+q_hi)
-      const float lo = __builtin_bit_cast(float, t << 16);
-      const float hi = __builtin_bit_cast(float, t & 0xffff0000u);
-      out[i] = pack2<bf16_tag>(fmaf(lo, s, c), fmaf(hi, s, c));  // (q - z) * s exact, then RN
-    }
+    for (int i = 0; i < 4; ++i) out[i] = pair(w, i);
   }
 };
 
@@ -39,13 +41,14 @@ struct W4Dq<f16_tag> {
     s2 = f16x2_t{v[0], v[0]};
     nzm2 = f16x2_t{-v[1], -v[1]};  // -(1024 + zero)
   }
+  __device__ __forceinline__ uint32_t pair(uint32_t w, int i) const {
+    const uint32_t t = ((w >> (4 * i)) & 0x000F000Fu) | 0x64006400u;  // (1024+q_lo, 1024+q_hi)
+    const f16x2_t d = __builtin_bit_cast(f16x2_t, t) + nzm2;          // q - z, exact
+    return __builtin_bit_cast(uint32_t, d * s2);                      // RN
+  }
   __device__ __forceinline__ void word(uint32_t w, uint32_t (&out)[4]) const {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t t = ((w >> (4 * i)) & 0x000F000Fu) | 0x64006400u;  // (1024+q_lo, 1024+q_hi)
-      const f16x2_t d = __builtin_bit_cast(f16x2_t, t) + nzm2;          // q - z, exact
-      out[i] = __builtin_bit_cast(uint32_t, d * s2);                    // RN
-    }
+    for (int i = 0; i < 4; ++i) out[i] = pair(w, i);
   }
 };
 
@@ -108,6 +111,6 @@ constexpr int W4_KC = 128;  // K granularity of the plan (split-K units, LDS chu
 
 // warp-specialised large-M kernel (w4_ws.hip): BM = 256, BN = 128, 512 threads
 void launch_gemm_ws(const GemmKParams& kp, int dtype, int ng, int n_blocks, hipStream_t st);
-constexpr size_t W4_WS_LDS_BYTES = 3 * (256 * 128 + 16 * 1024) + 2 * 4 * (1024 + 512);
+constexpr size_t W4_WS_LDS_BYTES = 7 * (256 * 64) + 4 * (8 * 1024) + 2 * 4 * (1024 + 512);
 
 }  // namespace slm

@@ -157,6 +157,47 @@ def test_llama3_8b_layer_shapes_awq(M, K, N):
     assert np.array_equal(got, helpers.f32_to_bf16_bits(w_ref))
 
 
+@pytest.mark.parametrize("bits", ["bf16", "f16"])
+def test_wave_specialised_kernel_grid(bits, monkeypatch):
+    """The M > 128 kernel (w4_ws.hip: 256 x 128 tiles, producer/consumer waves, LDS-DMA) forced on
+    small problems: ragged M (rows clamped, never stored), N not a multiple of 128 (clamped tiles),
+    K with 1..7 64-deep chunks past a multiple of the 8-chunk ring (zero-fragment tail), every
+    group size, both formats, act-order, bias, split-K (fp32 partials), fp16 and bf16."""
+    monkeypatch.setenv("SLM_W4_MT", "8")
+    i = 0
+    for M, N, K, gs, fmt, act, sk in (
+            (129, 128, 128, 128, "awq", False, 0), (256, 256, 512, 128, "gptq", False, 0),
+            (300, 160, 640, 32, "awq", False, 0), (200, 96, 1152, 64, "gptq", True, 0),
+            (257, 384, 2048, -1, "gptq", False, 0), (512, 256, 1024, 128, "awq", False, 2),
+            (256, 224, 1792, 128, "gptq", False, 7), (130, 128, 4096, 128, "awq", False, 4)):
+        i += 1
+        monkeypatch.setenv("SLM_W4_SPLITK", str(sk))
+        case = helpers.make_quant_case(700 + i, K, N, gs, fmt, bits, act_order=act)
+        out, ref = _run_gemm(case, bits, M, bias=(i % 2 == 1), seed=i)
+        err = _rel_err(out, ref)
+        assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, sk, err)
+
+
+def test_wave_specialised_kernel_matches_dense_on_prefill_shape():
+    """Default dispatch at a prefill-sized M picks the wave-specialised kernel; same identity as the
+    layer-shape test: int4_gemm(A) == dense_gemm(A, dequant(W)), plus strided A / C rows."""
+    from scalellm_amd import kernels
+    K, N, M = 4096, 28672, 384
+    case = helpers.make_quant_case(11, K, N, 128, "awq", "bf16")
+    packed = _pack(case, "bf16")
+    g = torch.Generator(device=DEV).manual_seed(3)
+    abuf = torch.randn(M, K + 64, device=DEV, dtype=torch.bfloat16, generator=g)
+    a = abuf[:, :K]
+    cbuf = torch.zeros(M, N + 8, device=DEV, dtype=torch.bfloat16)
+    c = cbuf[:, :N]
+    kernels.gptq_gemm(a, packed, c)
+    ref = a.float() @ kernels.w4_dequant(packed).float()
+    torch.cuda.synchronize()
+    assert float(cbuf[:, N:].abs().sum()) == 0.0
+    err = float((c.float() - ref).abs().mean() / ref.abs().mean())
+    assert err < 4e-3, err
+
+
 def test_gemm_linearity_and_strided_rows():
     # size-independent property: GEMM is linear in A; also A / C row strides (lda, ldc > width)
     from scalellm_amd import kernels
