@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(256) w4_splitk_reduce_kernel(const float* __re
 
 // ------------------------------- host side ------------------------------------------
 struct GemmPlan {
-  int mt, ntw, ng, pc, post, split_k, chunks_per_split, n_mblocks, n_nblocks;
+  int mt, ntw, ng, pc, post, small, split_k, chunks_per_split, n_mblocks, n_nblocks;
   size_t lds_bytes, part_bytes, aperm_bytes;
 };
 
@@ -471,7 +471,10 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
     const int64_t tiles4 = ((a->M + 127) / 128) * ((a->N + 127) / 128);
     mt = (tiles8 >= 112 && a_fits) ? 8 : ((tiles4 >= 256 || a->K >= 8192) ? 4 : 2);
   }
+  // M <= 32: the lean weight-streaming kernel (w4_small.hip)
+  pl->small = (a->M <= 32 && w4_env_int("SLM_W4_SMALL", 1) != 0) ? 1 : 0;
   mt = w4_env_int("SLM_W4_MT", mt);
+  if (pl->small) mt = 1;
   if (mt != 1 && mt != 2 && mt != 4 && mt != 8) mt = 4;  // 8 = wave-specialised kernel (w4_ws.hip)
   if (mt == 8 && ((a->M - 1) * a->lda + a->K) * 2 >= ((int64_t)1 << 31)) mt = 4;
   int ntw = w4_env_int("SLM_W4_NTW", 1);
@@ -659,7 +662,9 @@ SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream) {
   kp.n_chunks = (int)(a->K / W4_KC);
   kp.split_k = pl.split_k; kp.chunks_per_split = pl.chunks_per_split;
   kp.n_mblocks = pl.n_mblocks; kp.n_nblocks = pl.n_nblocks;
-  if (pl.mt == 8)
+  if (pl.small)
+    launch_gemm_small(kp, a->dtype, pl.ng, pl.n_nblocks * pl.n_mblocks * pl.split_k, st);
+  else if (pl.mt == 8)
     launch_gemm_ws(kp, a->dtype, pl.ng, pl.n_nblocks * pl.n_mblocks * pl.split_k, st);
   else if (a->dtype == SLM_BF16) launch_gemm<bf16_tag>(kp, pl, st);
   else launch_gemm<f16_tag>(kp, pl, st);

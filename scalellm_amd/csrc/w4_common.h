@@ -109,6 +109,10 @@ struct Mfma<f16_tag> {
 
 constexpr int W4_KC = 128;  // K granularity of the plan (split-K units, LDS chunk of the small-M kernels)
 
+// lean weight-streaming kernel for M <= 32 (w4_small.hip): BM = 32, BN = 128, 256 threads
+void launch_gemm_small(const GemmKParams& kp, int dtype, int ng, int n_blocks, hipStream_t st);
+constexpr size_t W4_SMALL_LDS_BYTES = 2 * 32 * 256;
+
 // warp-specialised large-M kernel (w4_ws.hip): BM = 256, BN = 128, 512 threads
 void launch_gemm_ws(const GemmKParams& kp, int dtype, int ng, int n_blocks, hipStream_t st);
 constexpr size_t W4_WS_LDS_BYTES = 7 * (256 * 64) + 4 * (8 * 1024) + 2 * 4 * (1024 + 512);

@@ -58,6 +58,8 @@ def main():
                                 itertools.product([4, 2], [0, 1, 2, 4, 8], [0, 1]) if not (mt == 4 and po)]
             graphs, ok = [], []
             for v in variants:
+                for k_ in [k for k in os.environ if k.startswith("SLM_W4_")]:
+                    del os.environ[k_]  # a variant sets ONLY its own knobs
                 for k_, val in v.items():
                     os.environ["SLM_W4_" + k_] = str(val)
                 kernels.gptq_gemm(x, packed, c)
