@@ -106,9 +106,28 @@ def measure_gemm(model, T):
     e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / n
     flops = 2.0 * T * L._packed.K * L._packed.N
+    # context only (not on the product path): the vendor library's DENSE bf16 GEMM of the same shape
+    # on the same GPU, timed the same way -- what "MFMA-bound" means in practice on this box
+    wd = torch.randn(L._packed.K, L._packed.N, device=model.device, dtype=model.dtype)
+    for _ in range(3):
+        torch.matmul(x, wd, out=out)
+    torch.cuda.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2):
+        for _ in range(n):
+            torch.matmul(x, wd, out=out)
+    g2.replay()
+    torch.cuda.synchronize()
+    e0.record()
+    g2.replay()
+    e1.record()
+    e1.synchronize()
+    us_dense = e0.elapsed_time(e1) * 1e3 / n
+    del wd
     return dict(shape=[T, L._packed.K, L._packed.N], us=round(us, 2),
                 tflops=round(flops / us / 1e6, 1),
-                frac_of_bf16_mfma_peak=round(flops / us / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4))
+                frac_of_bf16_mfma_peak=round(flops / us / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4),
+                hipblaslt_dense_bf16_same_shape_tflops=round(flops / us_dense / 1e6, 1))
 
 
 def cpu_baseline(model, tokens, params, sample_seqs, kv_len, block):

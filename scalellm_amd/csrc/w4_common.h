@@ -117,4 +117,9 @@ constexpr size_t W4_SMALL_LDS_BYTES = 2 * 32 * 256;
 void launch_gemm_ws(const GemmKParams& kp, int dtype, int ng, int n_blocks, hipStream_t st);
 constexpr size_t W4_WS_LDS_BYTES = 7 * (256 * 64) + 4 * (8 * 1024) + 2 * 4 * (1024 + 512);
 
+
+// symmetric 256 x 256 kernel for large M x N (w4_xl.hip): 512 threads, 160 KiB LDS
+void launch_gemm_xl(const GemmKParams& kp, int dtype, int ng, int n_blocks, hipStream_t st);
+constexpr size_t W4_XL_LDS_BYTES = 7 * (256 * 64) + 3 * (16 * 1024);
+
 }  // namespace slm

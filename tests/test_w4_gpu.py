@@ -178,6 +178,26 @@ def test_wave_specialised_kernel_grid(bits, monkeypatch):
         assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, sk, err)
 
 
+@pytest.mark.parametrize("bits", ["bf16", "f16"])
+def test_xl_256x256_kernel_grid(bits, monkeypatch):
+    """The symmetric 256 x 256 kernel (w4_xl.hip) forced on small problems: ragged M, N not a
+    multiple of 256 (clamped column tiles), K tails past a multiple of the 4-chunk ring, every
+    group size, both formats, act-order, bias, split-K."""
+    monkeypatch.setenv("SLM_W4_MT", "16")
+    i = 0
+    for M, N, K, gs, fmt, act, sk in (
+            (129, 256, 128, 128, "awq", False, 0), (256, 512, 512, 128, "gptq", False, 0),
+            (300, 160, 640, 32, "awq", False, 0), (200, 96, 1152, 64, "gptq", True, 0),
+            (257, 384, 2048, -1, "gptq", False, 0), (512, 256, 1024, 128, "awq", False, 2),
+            (256, 224, 1792, 128, "gptq", False, 7), (130, 288, 4096, 128, "awq", False, 4)):
+        i += 1
+        monkeypatch.setenv("SLM_W4_SPLITK", str(sk))
+        case = helpers.make_quant_case(900 + i, K, N, gs, fmt, bits, act_order=act)
+        out, ref = _run_gemm(case, bits, M, bias=(i % 2 == 1), seed=i)
+        err = _rel_err(out, ref)
+        assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, sk, err)
+
+
 def test_wave_specialised_kernel_matches_dense_on_prefill_shape():
     """Default dispatch at a prefill-sized M picks the wave-specialised kernel; same identity as the
     layer-shape test: int4_gemm(A) == dense_gemm(A, dequant(W)), plus strided A / C rows."""
