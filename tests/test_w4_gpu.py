@@ -218,6 +218,19 @@ def test_wave_specialised_kernel_matches_dense_on_prefill_shape():
     assert err < 4e-3, err
 
 
+@pytest.mark.parametrize("K,N,act", [(8192, 1280, False), (1024, 8192, False), (8192, 7168, False),
+                                     (3584, 8192, False), (1024, 8192, True)])
+def test_llama3_70b_tp8_rank_shapes_gptq(K, N, act):
+    """BASELINE config 3 (Llama-3-70B GPTQ int4 TP=8, bs=128): the per-rank GEMMs of SURVEY 8d --
+    symmetric GPTQ (stored zero 7 -> z = 8), group 128, fp16, one act-order case on the row-parallel
+    o_proj shard.  Checked against the fp32 oracle GEMM on the oracle's own dequantised weights."""
+    case = helpers.make_quant_case(K + N + int(act), K, N, 128, "gptq", "f16", act_order=act,
+                                   sym_zero=True)
+    out, ref = _run_gemm(case, "f16", 128, bias=False, seed=K)
+    err = _rel_err(out, ref)
+    assert err < GEMM_TOL["f16"], (K, N, act, err)
+
+
 def test_gemm_linearity_and_strided_rows():
     # size-independent property: GEMM is linear in A; also A / C row strides (lda, ldc > width)
     from scalellm_amd import kernels
