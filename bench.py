@@ -200,6 +200,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kv-fill", default="randn", choices=["tile", "randn"])
+    ap.add_argument("--advance", action="store_true", help="include the device-side input build "
+                    "(slm_decode_advance, SURVEY 8f f4) in the step: every replay appends one token "
+                    "per sequence, so kv_len grows by one per step from --seqlen")
     ap.add_argument("--simulate-tp", type=int, default=0, help="tuning aid: run rank 0's shard of a "
                     "TP=N step on one GPU with the collectives stubbed (flagged in the output)")
     args = ap.parse_args()
@@ -227,8 +230,10 @@ def main():
     if args.layers > 0 and args.layers != shape.n_layers:
         shape.n_layers, reduced = args.layers, True
     bs, L, B = args.bs, args.seqlen, args.block
-    shape.max_position = max(shape.max_position, L + 8)
-    tokens, positions, params, n_blocks = make_decode_inputs(bs, L, B, device, seed=1, vocab=shape.vocab)
+    shape.max_position = max(shape.max_position, L + 8 + (args.steps + 2 * args.warmup + 16 if args.advance else 0))
+    spare = ((args.steps + 2 * args.warmup + 8) // B + 2) if args.advance else 0
+    tokens, positions, params, n_blocks = make_decode_inputs(bs, L, B, device, seed=1, vocab=shape.vocab,
+                                                             spare_blocks=spare)
     t_init = time.perf_counter()
     model = LlamaDecodeStep(shape, bs, n_blocks, B, pa, quant_method=args.quant, group_size=128,
                             dtype=torch.bfloat16, device=device, seed=0, kv_fill=args.kv_fill)
@@ -241,6 +246,9 @@ def main():
     def step():
         nxt = model.forward(static_tokens, positions, params)
         static_tokens.copy_(nxt)  # greedy feedback: next step consumes this step's tokens
+        if args.advance:  # next step's positions / slots / kv_cu_lens built on the device (f4)
+            kernels.decode_advance(positions, params.kv_cu_seq_lens, params.new_cache_slots,
+                                   params.block_tables, params.cu_block_lens, B)
 
     for _ in range(max(args.warmup, 1)):
         step()
@@ -319,6 +327,7 @@ def main():
                        "global_batch": bs, "seq_len": L,
                        "parallelism": f"tp{world}" if world > 1 else "single-gpu",
                        "hip_graph": graph is not None, "reduced_model": reduced,
+                       "device_side_input_advance": bool(args.advance),
                        "simulated_tp_rank0_only": args.simulate_tp if args.simulate_tp > 1 else None,
                        "kv_cache_gib_per_gpu": round(2 * n_blocks * B * model.n_kv_heads * shape.head_dim
                                                      * 2 * shape.n_layers / 2 ** 30, 1),

@@ -218,6 +218,25 @@ SLM_API int slm_rope_kv_append(void* q /* [T, n_heads, D] in place */, int64_t q
 SLM_API int slm_silu_mul(void* out /* [T, d] */, const void* x /* [T, 2d]: gate | up */,
                          int64_t n_tokens, int64_t d, int32_t dtype, void* stream);
 
+/* ---- device-side input advance for the next decode step ----------------------
+ * Replaces, for a steady decode batch (q_len = 1 per sequence), the per-step host rebuild + H2D
+ * copies of Batch::prepare_model_input (engine/batch.cpp:97-255, model_runner.cpp:194-203):
+ * updates the graph's static input buffers IN PLACE on the device so a captured step can be
+ * replayed without touching the host.  For sequence b with len = positions[b] + 1 tokens cached:
+ *     positions[b]       <- len                                   (batch.cpp:155)
+ *     new_cache_slots[b] <- block_table[block_cu_lens[b] + len / B] + len % B
+ *                                                 (Sequence::kv_cache_slots, sequence.cpp:303-317)
+ *     kv_cu_lens[i]      <- kv_cu_lens[i] + i      for i = 0..n_seqs   (every length grows by 1)
+ * The block table is persistent: the host appends a block's first-slot id only when a sequence
+ * crosses a block boundary; a missing block (len / B >= blocks of b) sets *overflow_flag |= 1 and
+ * clamps the slot to the sequence's last block (the step must then be discarded by the host).
+ * q_cu_lens is unchanged.  block_size must be a power of two.  Bit-exact integer contract. */
+SLM_API int slm_decode_advance(int32_t* positions /* [n_seqs] */, int32_t* kv_cu_lens /* [n_seqs+1] */,
+                               int32_t* new_cache_slots /* [n_seqs] */,
+                               const int32_t* block_table, const int32_t* block_cu_lens /* [n_seqs+1] */,
+                               int32_t n_seqs, int32_t block_size, int32_t* overflow_flag /* [1], may be NULL */,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

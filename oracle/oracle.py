@@ -67,6 +67,20 @@ def all_slots(block_table, block_cu_lens, kv_cu_lens, block_size: int) -> np.nda
     return out
 
 
+def decode_advance(positions, kv_cu_lens, block_table, block_cu_lens, block_size: int):
+    """Next decode step's (positions, kv_cu_lens, new_cache_slots, n_missing_blocks) from the
+    current step's inputs (q_len = 1 per sequence)."""
+    pos = _i32(positions).copy()
+    kcu = _i32(kv_cu_lens).copy()
+    bt, bcu = _i32(block_table), _i32(block_cu_lens)
+    slots = np.zeros(len(pos), np.int32)
+    fn = lib().oracle_decode_advance
+    fn.restype = C.c_int32
+    missing = fn(_p(pos, _i32p), _p(kcu, _i32p), _p(slots, _i32p), _p(bt, _i32p), _p(bcu, _i32p),
+                 C.c_int32(len(pos)), C.c_int32(block_size))
+    return pos, kcu, slots, int(missing)
+
+
 def set_kv_cache(slot_ids, keys: np.ndarray, values: np.ndarray, key_cache: np.ndarray,
                  value_cache: np.ndarray) -> None:
     """In-place scatter (any element type; rows are [n_kv_heads, head_dim])."""

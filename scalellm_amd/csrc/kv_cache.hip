@@ -40,6 +40,30 @@ __global__ void __launch_bounds__(256) set_kv_cache_kernel(
   }
 }
 
+// decode-step input advance: every thread touches only its own elements, so the
+// update is race-free in place
+__global__ void __launch_bounds__(256) decode_advance_kernel(
+    int32_t* __restrict__ positions, int32_t* __restrict__ kv_cu_lens,
+    int32_t* __restrict__ new_cache_slots, const int32_t* __restrict__ block_table,
+    const int32_t* __restrict__ block_cu_lens, int32_t n_seqs, int32_t shift, int32_t mask,
+    int32_t* __restrict__ overflow_flag) {
+  const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > n_seqs) return;
+  if (b < n_seqs) {
+    const int32_t len = positions[b] + 1;  // tokens already in the cache = position of the new token
+    const int32_t base = block_cu_lens[b];
+    const int32_t nblk = block_cu_lens[b + 1] - base;
+    int32_t blk = len >> shift;
+    if (blk >= nblk) {  // the host has not appended the block yet
+      if (overflow_flag) atomicOr(overflow_flag, 1);
+      blk = nblk > 0 ? nblk - 1 : 0;
+    }
+    positions[b] = len;
+    new_cache_slots[b] = block_table[base + blk] + (len & mask);
+  }
+  kv_cu_lens[b] += b;  // b = 0 .. n_seqs: every sequence before this offset grew by one token
+}
+
 }  // namespace slm
 
 using namespace slm;
@@ -78,5 +102,22 @@ extern "C" SLM_API int slm_set_kv_cache(const int32_t* slot_ids, const void* key
     hipLaunchKernelGGL(set_kv_cache_kernel<2>, dim3(grid), dim3(256), 0, st, slot_ids,
                        (const char*)keys, (const char*)values, ksb, vsb, (char*)key_cache,
                        (char*)value_cache, n_tokens, row_bytes, lpr, rows_per_block);
+  return hip_check_launch();
+}
+
+extern "C" SLM_API int slm_decode_advance(int32_t* positions, int32_t* kv_cu_lens,
+                                          int32_t* new_cache_slots, const int32_t* block_table,
+                                          const int32_t* block_cu_lens, int32_t n_seqs,
+                                          int32_t block_size, int32_t* overflow_flag, void* stream) {
+  if (n_seqs == 0) return SLM_OK;
+  if (!positions || !kv_cu_lens || !new_cache_slots || !block_table || !block_cu_lens || n_seqs < 0)
+    return SLM_ERR_INVALID_ARG;
+  if (block_size <= 0 || !is_pow2(block_size)) return SLM_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hip_clear_error();
+  const dim3 grid((unsigned)((n_seqs + 1 + 255) / 256)), blk(256);
+  hipLaunchKernelGGL(decode_advance_kernel, grid, blk, 0, st, positions, kv_cu_lens, new_cache_slots,
+                     block_table, block_cu_lens, n_seqs, ilog2(block_size), block_size - 1,
+                     overflow_flag);
   return hip_check_launch();
 }

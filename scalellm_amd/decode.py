@@ -230,12 +230,13 @@ class LlamaDecodeStep:
 
 
 def make_decode_inputs(batch: int, kv_len: int, block_size: int, device, seed: int = 0,
-                       q_len: int = 1, vocab: int = 128256):
+                       q_len: int = 1, vocab: int = 128256, spare_blocks: int = 0):
     """Synthetic decode batch in the engine's input format (engine/batch.cpp:77-270): every
     sequence has kv_len tokens of history INCLUDING the q_len new ones; blocks are a seeded
-    random permutation (unique ids), block table = first-slot ids."""
+    random permutation (unique ids), block table = first-slot ids.  `spare_blocks` extra blocks per
+    sequence are already in the table (room for kernels.decode_advance to grow the sequences)."""
     g = torch.Generator(device=device).manual_seed(seed)
-    nblk_seq = (kv_len + block_size - 1) // block_size
+    nblk_seq = (kv_len + block_size - 1) // block_size + spare_blocks
     n_blocks = batch * nblk_seq + 2
     perm = torch.randperm(n_blocks - 1, device=device, generator=g)[:batch * nblk_seq] + 1
     table = (perm * block_size).to(torch.int32)

@@ -180,6 +180,30 @@ def set_kv_cache(slot_ids: torch.Tensor, keys: torch.Tensor, values: torch.Tenso
                              _dtype_code(keys), _stream()), "slm_set_kv_cache")
 
 
+def decode_advance(positions: torch.Tensor, kv_cu_lens: torch.Tensor, new_cache_slots: torch.Tensor,
+                   block_table: torch.Tensor, block_cu_lens: torch.Tensor, block_size: int,
+                   overflow_flag: torch.Tensor | None = None) -> None:
+    """Device-side input build for the next decode step: in-place update of the
+    graph's static int32 inputs, replacing the per-step host rebuild + H2D copies of
+    Batch::prepare_model_input (engine/batch.cpp:97-255, model_runner.cpp:194-203) for a steady
+    decode batch.  Slot arithmetic = Sequence::kv_cache_slots (request/sequence.cpp:303-317)."""
+    L = _lib.lib()
+    ts = [positions, kv_cu_lens, new_cache_slots, block_table, block_cu_lens]
+    if overflow_flag is not None:
+        ts.append(overflow_flag)
+    _require_gpu(*ts)
+    for t in ts:
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise SlmError("decode_advance: all index tensors must be contiguous int32")
+    n = positions.numel()
+    if kv_cu_lens.numel() != n + 1 or block_cu_lens.numel() != n + 1 or new_cache_slots.numel() != n:
+        raise SlmError("decode_advance: inconsistent batch sizes")
+    check(L.slm_decode_advance(positions.data_ptr(), kv_cu_lens.data_ptr(), new_cache_slots.data_ptr(),
+                               block_table.data_ptr(), block_cu_lens.data_ptr(), n, block_size,
+                               overflow_flag.data_ptr() if overflow_flag is not None else None,
+                               _stream()), "slm_decode_advance")
+
+
 # ---------------------------------------------------------------------------------------
 # int4 (AWQ / GPTQ) prepack + GEMM
 # ---------------------------------------------------------------------------------------

@@ -71,3 +71,52 @@ def test_append_then_attend_two_step_decode():
                                 np.arange(kv_len, dtype=np.int32), [0, kv_len], 1, D ** -0.5)
         np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=1e-2, atol=1e-2)
         pos += n_new
+
+
+def test_decode_advance_bit_exact_and_graph_replay():
+    """f4 (slm_decode_advance): in-place device update of the static decode inputs == the oracle's
+    restatement of the host rebuild, over 50 steps, eagerly and as a replayed hipGraph; a missing
+    block raises the overflow flag."""
+    from scalellm_amd import kernels
+    rng = np.random.default_rng(11)
+    B, bs = 16, 300  # > 256: more than one workgroup
+    lens = rng.integers(1, 500, size=bs)
+    cap = [int((l + 60) // B + 1) for l in lens]
+    ids = rng.permutation(sum(cap) + 13)[:sum(cap)].astype(np.int32)
+    bcu = np.concatenate([[0], np.cumsum(cap)]).astype(np.int32)
+    table = (ids * B).astype(np.int32)
+    pos = (lens - 1).astype(np.int32)
+    kcu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    d = lambda a: torch.from_numpy(a.copy()).to(DEV)
+    pos_d, kcu_d, slots_d = d(pos), d(kcu), torch.zeros(bs, dtype=torch.int32, device=DEV)
+    table_d, bcu_d = d(table), d(bcu)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for step in range(10):
+        kernels.decode_advance(pos_d, kcu_d, slots_d, table_d, bcu_d, B, flag)
+        pos, kcu, slots, missing = oracle.decode_advance(pos, kcu, table, bcu, B)
+        assert missing == 0
+        np.testing.assert_array_equal(pos_d.cpu().numpy(), pos)
+        np.testing.assert_array_equal(kcu_d.cpu().numpy(), kcu)
+        np.testing.assert_array_equal(slots_d.cpu().numpy(), slots)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        kernels.decode_advance(pos_d, kcu_d, slots_d, table_d, bcu_d, B, flag)
+    pos, kcu, slots, _ = oracle.decode_advance(pos, kcu, table, bcu, B)  # the capture itself does not run
+    for step in range(40):
+        g.replay()
+        pos, kcu, slots, missing = oracle.decode_advance(pos, kcu, table, bcu, B)
+        assert missing == 0
+    torch.cuda.synchronize()
+    # capture executed nothing, so the device is one step behind the host bookkeeping above
+    pos_d2 = pos_d.cpu().numpy()
+    np.testing.assert_array_equal(pos_d2 + 1, pos)
+    g.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(pos_d.cpu().numpy(), pos)
+    np.testing.assert_array_equal(kcu_d.cpu().numpy(), kcu)
+    np.testing.assert_array_equal(slots_d.cpu().numpy(), slots)
+    assert int(flag.item()) == 0
+    # run one sequence past its last block: flag set, slot clamped inside the sequence's blocks
+    for _ in range(80):
+        kernels.decode_advance(pos_d, kcu_d, slots_d, table_d, bcu_d, B, flag)
+    assert int(flag.item()) == 1

@@ -144,3 +144,30 @@ def test_numpy_packers_match_reference_format():
             gi = np.arange(q.shape[0]) // gs
             w = c["scales"].astype(np.float32)[gi] * (q - z[gi])
             np.testing.assert_array_equal(w.astype(np.float32), c["w"])
+
+
+def test_decode_advance_matches_a_full_host_rebuild():
+    """f4: the incremental next-step inputs equal what the reference rebuilds from scratch every
+    step (Batch::prepare_model_input, engine/batch.cpp:97-255): positions = tokens cached, slot =
+    blocks[pos / B].id * B + pos % B (sequence.cpp:303-317), kv_cu_lens = cumsum(len + 1)."""
+    rng = np.random.default_rng(5)
+    B, bs = 16, 9
+    lens = rng.integers(1, 200, size=bs)
+    cap = [int((l + 40) // B + 1) for l in lens]                      # blocks held per sequence
+    ids = rng.permutation(sum(cap) + 7)[:sum(cap)].astype(np.int32)   # unique shuffled block ids
+    bcu = np.concatenate([[0], np.cumsum(cap)]).astype(np.int32)
+    table = (ids * B).astype(np.int32)                                # first-slot ids (batch.cpp:206-209)
+    pos = (lens - 1).astype(np.int32)                                 # position of the last processed token
+    kcu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    for _ in range(40):
+        pos, kcu, slots, missing = oracle.decode_advance(pos, kcu, table, bcu, B)
+        lens = lens + 1
+        assert missing == 0
+        np.testing.assert_array_equal(pos, lens - 1)
+        np.testing.assert_array_equal(kcu, np.concatenate([[0], np.cumsum(lens)]))
+        want = [ids[bcu[b] + (lens[b] - 1) // B] * B + (lens[b] - 1) % B for b in range(bs)]
+        np.testing.assert_array_equal(slots, np.asarray(want, np.int32))
+    # a sequence that runs out of blocks is reported, not silently mis-addressed
+    pos2 = np.asarray([B * cap[0] - 1], np.int32)
+    _, _, _, missing = oracle.decode_advance(pos2, np.asarray([0, B * cap[0]], np.int32), table, bcu[:2], B)
+    assert missing == 1
