@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(256) w4_splitk_reduce_kernel(const float* __re
 
 // ------------------------------- host side ------------------------------------------
 struct GemmPlan {
-  int mt, ntw, ng, pc, post, small, split_k, chunks_per_split, n_mblocks, n_nblocks;
+  int mt, ntw, ng, pc, post, small, gemv, split_k, chunks_per_split, n_mblocks, n_nblocks;
   size_t lds_bytes, part_bytes, aperm_bytes;
 };
 
@@ -476,7 +476,12 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
     const int64_t rounds = (tiles16 + 255) / 256;
     if (a_fits && tiles16 >= 224 && tiles16 * 100 >= rounds * 256 * 87) mt = 16;
   }
-  // M <= 32: the lean weight-streaming kernel (w4_small.hip)
+  // M <= 4: dot2 GEMV (w4_gemv.hip); M <= 32: the lean weight-streaming kernel (w4_small.hip)
+  // (measured: the GEMV wins on every layer shape at M = 1 and loses on some at M = 2..4, so the
+  // default is M = 1 only; SLM_W4_GEMV=2 forces it for M <= 4; its 32-bit offsets need < 4 GiB tables)
+  const int gemv_mode = w4_env_int("SLM_W4_GEMV", 1);
+  pl->gemv = (gemv_mode != 0 && (a->M == 1 || gemv_mode == 2) && gemv_supported(a->M, a->K, gs) &&
+              a->K * a->N / 2 < ((int64_t)1 << 32) && (a->K / gs) * a->N * 4 < ((int64_t)1 << 32)) ? 1 : 0;
   pl->small = (a->M <= 32 && w4_env_int("SLM_W4_SMALL", 1) != 0) ? 1 : 0;
   mt = w4_env_int("SLM_W4_MT", mt);
   if (pl->small) mt = 1;
@@ -519,6 +524,10 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   // small-M tiles use the post-scaled form (7 VALU per 8 weights instead of ~27)
   pl->post = w4_env_int("SLM_W4_POST", a->M <= 64 ? 1 : 0) != 0 && mt <= 2;
   pl->lds_bytes = (size_t)2 * pc * bm * 256 + (pl->post ? (size_t)2 * pc * pl->ng * bm * sizeof(float) : 0);
+  if (pl->gemv) {  // K is split inside the workgroup: no partials, no reduce launch
+    pl->split_k = 1;
+    pl->chunks_per_split = n_chunks;
+  }
   pl->part_bytes = pl->split_k > 1 ? (size_t)pl->split_k * a->M * a->N * sizeof(float) : 0;
   pl->aperm_bytes = a->perm ? (((size_t)a->M * a->K * 2 + 255) & ~(size_t)255) : 0;
   return SLM_OK;
@@ -668,7 +677,9 @@ SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream) {
   kp.n_chunks = (int)(a->K / W4_KC);
   kp.split_k = pl.split_k; kp.chunks_per_split = pl.chunks_per_split;
   kp.n_mblocks = pl.n_mblocks; kp.n_nblocks = pl.n_nblocks;
-  if (pl.small)
+  if (pl.gemv)
+    launch_gemv(kp, a->dtype, pl.ng, st);
+  else if (pl.small)
     launch_gemm_small(kp, a->dtype, pl.ng, pl.n_nblocks * pl.n_mblocks * pl.split_k, st);
   else if (pl.mt == 16)
     launch_gemm_xl(kp, a->dtype, pl.ng, pl.n_nblocks * pl.n_mblocks * pl.split_k, st);
