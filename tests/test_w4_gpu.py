@@ -231,6 +231,26 @@ def test_llama3_70b_tp8_rank_shapes_gptq(K, N, act):
     assert err < GEMM_TOL["f16"], (K, N, act, err)
 
 
+@pytest.mark.parametrize("bits", ["bf16", "f16"])
+def test_dot2_gemv_kernel_grid(bits, monkeypatch):
+    """The M <= 4 dot2 GEMV (w4_gemv.hip; default for M = 1, forced here for M = 2..4): every group
+    size incl. per-channel (a K slice then holds part of a group: partial activation sums), K not a
+    multiple of the 8-way slicing, N not a multiple of the column tiles per workgroup, both formats,
+    act-order, bias, rows beyond M never stored."""
+    monkeypatch.setenv("SLM_W4_GEMV", "2")
+    i = 0
+    for M, N, K, gs, fmt, act in (
+            (1, 64, 128, 128, "awq", False), (1, 4096, 4096, 128, "awq", False),
+            (2, 160, 640, 32, "gptq", False), (3, 96, 1152, 64, "gptq", True),
+            (4, 384, 2048, -1, "gptq", False), (1, 256, 14336, 128, "awq", False),
+            (1, 224, 1792, 256, "gptq", False), (4, 288, 4096, 128, "awq", False)):
+        i += 1
+        case = helpers.make_quant_case(1300 + i, K, N, gs, fmt, bits, act_order=act)
+        out, ref = _run_gemm(case, bits, M, bias=(i % 2 == 1), seed=i)
+        err = _rel_err(out, ref)
+        assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, err)
+
+
 def test_gemm_linearity_and_strided_rows():
     # size-independent property: GEMM is linear in A; also A / C row strides (lda, ldc > width)
     from scalellm_amd import kernels
