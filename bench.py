@@ -29,7 +29,11 @@ import os
 import sys
 import time
 
-import torch
+# RCCL / cross-process GPU memory sharing on this platform needs dmabuf IPC (see the environment
+# notes); harmless when already exported
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -186,7 +190,50 @@ def cpu_baseline(model, tokens, params, sample_seqs, kv_len, block):
                         f"{reps} reps, {t_layer:.2f} s/layer-sample, extrapolated x{s.n_layers} layers"))
 
 
+def _probe_capture_main():
+    """Child-process probe (bench.py --probe-capture): can an RCCL all-reduce be captured into a
+    hipGraph on this box?  A FAILED capture cannot be recovered from inside a process with this
+    torch build (every later HIP call re-raises hipErrorStreamCaptureInvalidated and the interpreter
+    aborts at exit), so the question is asked in throw-away processes with their own process group."""
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    torch.distributed.init_process_group(backend="nccl", device_id=dev)
+    t = torch.ones(1 << 20, device=dev, dtype=torch.bfloat16)
+    torch.distributed.all_reduce(t)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        torch.distributed.all_reduce(t)
+    g.replay()
+    torch.cuda.synchronize()
+    torch.distributed.barrier()
+    print("PROBE_CAPTURE_OK", flush=True)
+    os._exit(0)  # skip teardown: nothing here is worth a clean shutdown
+
+
+def rccl_capture_works(world: int, device) -> bool:
+    """All ranks: spawn the probe child, wait, and agree (MIN over ranks) on the answer."""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 7)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)  # the probe's rank 0 hosts its own store
+    ok = 0
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-capture"], env=env,
+                           capture_output=True, text=True, timeout=240)
+        ok = 1 if (r.returncode == 0 and "PROBE_CAPTURE_OK" in r.stdout) else 0
+    except Exception:  # noqa: BLE001 -- timeout or spawn failure = "no"
+        ok = 0
+    t = torch.tensor([ok], device=device, dtype=torch.int32)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+    return bool(t.item())
+
+
 def main():
+    if "--probe-capture" in sys.argv:
+        _probe_capture_main()
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -209,7 +256,9 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # SLM_FORCE_LOCAL_RANK: smoke-testing the N > 1 code path on a 1-GPU box (all ranks on cuda:0,
+    # SLM_DIST_BACKEND=gloo); never set by the driver
+    local_rank = int(os.environ.get("SLM_FORCE_LOCAL_RANK", os.environ.get("LOCAL_RANK", "0")))
     if world != args.gpus:
         if args.gpus != 1 or world != 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torchrun "
@@ -255,10 +304,19 @@ def main():
     torch.cuda.synchronize()
 
     graph = None
+    if world > 1 and torch.distributed.get_backend() != "nccl":
+        args.no_graph = True  # only RCCL collectives can be captured
+    elif world > 1 and not args.no_graph and not rccl_capture_works(world, device):
+        args.no_graph = True
+        if rank == 0:
+            print("[bench] RCCL all-reduce cannot be captured into a hipGraph here (probe failed): "
+                  "running the step eagerly", file=sys.stderr)
     if not args.no_graph:
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: with RCCL in the step (N > 1) the process group's watchdog thread keeps
+            # querying events; a global-mode capture would be invalidated by those calls
+            with torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global"):
                 step()
             g.replay()
             torch.cuda.synchronize()
@@ -268,7 +326,14 @@ def main():
                 print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly",
                       file=sys.stderr)
             graph = None
-            torch.cuda.synchronize()
+            # a failed capture leaves a stale HIP error behind that the next call would re-raise:
+            # drain it (each failing call consumes it) before running eagerly
+            for _ in range(4):
+                try:
+                    torch.cuda.synchronize()
+                    break
+                except Exception:  # noqa: BLE001
+                    pass
     run = graph.replay if graph is not None else step
     for _ in range(args.warmup):
         run()
