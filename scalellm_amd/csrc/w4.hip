@@ -482,7 +482,9 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   const int gemv_mode = w4_env_int("SLM_W4_GEMV", 1);
   pl->gemv = (gemv_mode != 0 && (a->M == 1 || gemv_mode == 2) && gemv_supported(a->M, a->K, gs) &&
               a->K * a->N / 2 < ((int64_t)1 << 32) && (a->K / gs) * a->N * 4 < ((int64_t)1 << 32)) ? 1 : 0;
-  pl->small = (a->M <= 32 && w4_env_int("SLM_W4_SMALL", 1) != 0) ? 1 : 0;
+  pl->small = (a->M <= 32 && w4_env_int("SLM_W4_SMALL", 1) != 0 &&
+               a->K * a->N / 2 < ((int64_t)1 << 32) && (a->K / gs) * a->N * 4 < ((int64_t)1 << 32) &&
+               ((a->M - 1) * a->lda + a->K) * 2 < ((int64_t)1 << 31)) ? 1 : 0;
   mt = w4_env_int("SLM_W4_MT", mt);
   if (pl->small) mt = 1;
   // 8 = wave-specialised 256 x 128 kernel (w4_ws.hip), 16 = symmetric 256 x 256 kernel (w4_xl.hip)

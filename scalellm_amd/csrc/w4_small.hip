@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256, 2) w4a16_gemm_small_kernel(const GemmKPar
   // cap the weight ring at two chunks in flight; a three-iterations-old one costs nothing.
   u32x4 areg[SM_RING][2];
   auto a_load = [&](int c, u32x4 (&dst)[2]) {
-    const int64_t off = (int64_t)clampc(c) * 256;
+    const uint32_t off = (uint32_t)clampc(c) * 256u;  // < 2 GiB: checked on the host
 #pragma unroll
     for (int i = 0; i < 2; ++i) dst[i] = *reinterpret_cast<const u32x4*>(a_src[i] + off);
   };
@@ -108,20 +108,23 @@ __global__ void __launch_bounds__(256, 2) w4a16_gemm_small_kernel(const GemmKPar
   // ---- weight / scale rings ----
   u32x4 wreg[SM_RING][2];
   uint32_t szreg[SM_RING][NG];
-  // per-lane bases once; per load only a wave-uniform (scalar) offset is added
-  const uint32_t* wlane = p.wq + (nt * 64 + lane) * 4;
-  const uint32_t* szlane = p.sz + nt * 32 + (lane & 31);
-  const int64_t wstride = n_tiles * 256;  // u32 per 64-deep half chunk
+  // per-lane bases once; per load only a wave-uniform 32-bit byte offset is added (the host checks
+  // that the packed weights and the scale table are < 4 GiB): scalar address math is issue slots too
+  const char* wlane = reinterpret_cast<const char*>(p.wq + (nt * 64 + lane) * 4);
+  const char* szlane = reinterpret_cast<const char*>(p.sz + nt * 32 + (lane & 31));
+  const uint32_t wstride = (uint32_t)(n_tiles * 1024);  // bytes per 64-deep half chunk
+  const uint32_t szstride = (uint32_t)(p.N * 4);        // bytes per scale group
+  const int cpg_shift = p.gs_shift >= 30 ? 30 : (p.gs_shift > 7 ? p.gs_shift - 7 : 0);  // log2(chunks per group)
   auto w_load = [&](int c, u32x4 (&w)[2], uint32_t (&sz)[NG]) {
-    const int cc = clampc(c);
+    const uint32_t cc = (uint32_t)clampc(c);
 #pragma unroll
     for (int h = 0; h < 2; ++h)
       w[h] = __builtin_nontemporal_load(
-          reinterpret_cast<const u32x4*>(wlane + (int64_t)(cc * 2 + h) * wstride));
+          reinterpret_cast<const u32x4*>(wlane + (cc * 2 + h) * wstride));
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      const int64_t grp = ((int64_t)cc * W4_KC + g * (W4_KC / NG)) >> p.gs_shift;
-      sz[g] = szlane[grp * p.N];
+      const uint32_t grp = NG > 1 ? cc * NG + g : (cc >> cpg_shift);
+      sz[g] = *reinterpret_cast<const uint32_t*>(szlane + grp * szstride);
     }
   };
 
@@ -166,8 +169,7 @@ __global__ void __launch_bounds__(256, 2) w4a16_gemm_small_kernel(const GemmKPar
         const char* sbase = smem + stage * SM_STAGE_BYTES + a_row;
         // does the scale group that ends this chunk end HERE (groups >= 128 may span chunks)
         const int cabs = c0 + i;
-        const bool grp_ends = !SPAN || i == nC - 1 ||
-                              (((int64_t)(cabs + 1) * W4_KC) >> p.gs_shift) != (((int64_t)cabs * W4_KC) >> p.gs_shift);
+        const bool grp_ends = !SPAN || i == nC - 1 || ((cabs + 1) >> cpg_shift) != (cabs >> cpg_shift);
         frag_t af = __builtin_bit_cast(
             frag_t, *reinterpret_cast<const u32x4*>(sbase + (((0 * 2 + kh) ^ a_swz) << 4)));
 #pragma unroll
