@@ -25,6 +25,15 @@
 //    per 128-deep K chunk through XOR-swizzled LDS (conflict-free ds_read_b128); weights go
 //    HBM -> registers -> dequant -> MFMA B operand; fp32 accumulate; optional split-K with fp32
 //    partials + reduce (bias added after the reduction, as qlinear_awq_marlin_impl.cpp:357-363).
+//
+// This file holds the prepack / dequant kernels, the GENERAL GEMM kernel (32..128-row tiles) and the
+// one entry point, slm_w4a16_gemm, whose plan picks among five kernels by (M, N, K):
+//    M == 1                          w4_gemv.hip   dot2 GEMV, K split inside the workgroup
+//    M <= 32                         w4_small.hip  lean weight stream (MFMA, post-scaled)
+//    32 < M <= 128, narrow layers    this file
+//    M > 128, >= 112 tiles of 256x128 w4_ws.hip     producer / consumer waves, LDS-DMA activations
+//    prefill-sized M x N             w4_xl.hip     symmetric 256 x 256 tiles
+// (DESIGN.md 3.3 has the measurements behind each boundary.)
 #include "w4_common.h"
 
 namespace slm {
