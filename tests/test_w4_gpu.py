@@ -251,6 +251,30 @@ def test_dot2_gemv_kernel_grid(bits, monkeypatch):
         assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, err)
 
 
+@pytest.mark.parametrize("M,K,N,env", [(256, 2048, 28672, {"SLM_W4_MT": "8"}),
+                                       (384, 4096, 4096, {"SLM_W4_MT": "8", "SLM_W4_SPLITK": "4"}),
+                                       (512, 2048, 8192, {"SLM_W4_MT": "16"}),
+                                       (32, 4096, 6144, {}), (1, 4096, 6144, {})])
+def test_repeated_launches_are_bit_identical(M, K, N, env, monkeypatch):
+    """The wave-specialised / 256x256 / small-M / GEMV kernels synchronise with bare s_barriers,
+    counted vmcnt/lgkmcnt waits and LDS rings: a protocol error would show up as run-to-run
+    differences.  30 back-to-back launches (no host sync in between) must agree bit for bit."""
+    from scalellm_amd import kernels
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    case = helpers.make_quant_case(M + K + N, K, N, 128, "awq", "bf16")
+    packed = _pack(case, "bf16")
+    g = torch.Generator(device=DEV).manual_seed(M)
+    a = torch.randn(M, K, device=DEV, dtype=torch.bfloat16, generator=g)
+    outs = []
+    for _ in range(30):
+        c = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        kernels.gptq_gemm(a, packed, c)
+        outs.append(c)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
 def test_gemm_linearity_and_strided_rows():
     # size-independent property: GEMM is linear in A; also A / C row strides (lda, ldc > width)
     from scalellm_amd import kernels
