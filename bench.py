@@ -284,8 +284,19 @@ def main():
     tokens, positions, params, n_blocks = make_decode_inputs(bs, L, B, device, seed=1, vocab=shape.vocab,
                                                              spare_blocks=spare)
     t_init = time.perf_counter()
+    # N > 1: the two row-parallel reductions per layer run as the xGMI all-reduce fused with the
+    # residual add + RMSNorm when every rank can map its peers AND the start-up
+    # self-test reproduces the sequential sum bit for bit; otherwise RCCL all-reduce + slm_rms_norm.
+    # SLM_CUSTOM_AR=0 forces the RCCL path.
+    custom_ar = None
+    if world > 1 and args.simulate_tp <= 1 and os.environ.get("SLM_CUSTOM_AR", "1") != "0":
+        from scalellm_amd.custom_allreduce import try_create_xgmi_allreduce
+        custom_ar = try_create_xgmi_allreduce(
+            pg.rank, pg.world_size, bs, shape.hidden, torch.bfloat16, device,
+            log=lambda m: print(f"[bench] {m}", file=sys.stderr))
     model = LlamaDecodeStep(shape, bs, n_blocks, B, pa, quant_method=args.quant, group_size=128,
-                            dtype=torch.bfloat16, device=device, seed=0, kv_fill=args.kv_fill)
+                            dtype=torch.bfloat16, device=device, seed=0, kv_fill=args.kv_fill,
+                            custom_allreduce=custom_ar)
     model.reserve_workspaces(bs, L)
     torch.cuda.synchronize()
     t_init = time.perf_counter() - t_init
@@ -392,6 +403,9 @@ def main():
                        "global_batch": bs, "seq_len": L,
                        "parallelism": f"tp{world}" if world > 1 else "single-gpu",
                        "hip_graph": graph is not None, "reduced_model": reduced,
+                       "row_parallel_reduce": (None if world == 1 else
+                                               "xgmi two-shot all-reduce fused with residual+rmsnorm"
+                                               if custom_ar is not None else "rccl all-reduce + rms_norm"),
                        "device_side_input_advance": bool(args.advance),
                        "simulated_tp_rank0_only": args.simulate_tp if args.simulate_tp > 1 else None,
                        "kv_cache_gib_per_gpu": round(2 * n_blocks * B * model.n_kv_heads * shape.head_dim

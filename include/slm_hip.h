@@ -14,7 +14,8 @@
  *   - device pointers unless stated "host";
  *   - asynchronous on `stream` (a hipStream_t passed as void*); never
  *     synchronises, never allocates, never reads device memory on the host --
- *     therefore safe under hipGraph stream capture
+ *     therefore safe under hipGraph stream capture (the only exceptions are the
+ *     init-time slm_shm_* / slm_ar_read_error helpers of section 6, marked there)
  *     (reference: src/engine/model_runner.cpp:141-178);
  *   - returns 0 (SLM_OK) or a negative slm_status; never aborts;
  *   - thread-safe per stream (one Worker thread per GPU in the reference:
@@ -236,6 +237,75 @@ SLM_API int slm_decode_advance(int32_t* positions /* [n_seqs] */, int32_t* kv_cu
                                const int32_t* block_table, const int32_t* block_cu_lens /* [n_seqs+1] */,
                                int32_t n_seqs, int32_t block_size, int32_t* overflow_flag /* [1], may be NULL */,
                                void* stream);
+
+/* ========================================================================== */
+/* 6. xGMI all-reduce fused with residual-add + RMSNorm    */
+/*    replaces  ProcessGroupNCCL::allreduce  (ncclAllReduce SUM, in place)    */
+/*              src/model_parallel/process_group.cpp:135-153                  */
+/*    callers   reduce_from_model_parallel_region, model_parallel.cpp:33-44,  */
+/*              from the row-parallel linears (qlinear_awq_marlin_impl.cpp    */
+/*              :357-363), followed in the decoder layer by                   */
+/*              kernel::rms_norm_residual (layernorm_kernels.cu:125).         */
+/*                                                                            */
+/* Two-shot all-reduce in ONE launch per rank over peer-mapped buffers: every */
+/* rank owns ceil(M / world) consecutive ROWS of the [M, H] message; it reads */
+/* its rows of every rank's partial sum over xGMI, adds them in fp32 in rank  */
+/* order (so all ranks hold bit-identical results), rounds to T, optionally   */
+/* applies   h = x + residual; residual = T(h); y = T(h * rsqrt(mean h^2 +    */
+/* eps)) * weight   (normalization.h:42-52, same arithmetic as slm_rms_norm)  */
+/* to those rows, publishes them in place in its own buffer, and after one    */
+/* cross-rank flag barrier gathers every other rank's rows into `out`.  The   */
+/* residual stream stays row-sharded: a rank only ever touches its own rows.  */
+/* Synchronisation: per-workgroup monotonically increasing flags in           */
+/* peer-writable UNCACHED signal blocks (no host involvement, no reset, graph */
+/* replay safe); bounded spins -- a peer that never arrives raises            */
+/* SLM_AR_ERR_TIMEOUT in the signal block's error word instead of hanging.    */
+/* ========================================================================== */
+#define SLM_AR_MAX_RANKS 8
+#define SLM_AR_MAX_BLOCKS 128
+#define SLM_SHM_HANDLE_BYTES 64
+#define SLM_AR_ERR_TIMEOUT 1
+
+/* Host-side set-up helpers (init time only; these DO allocate / map and are not capture-safe):
+ * peer-shareable device memory and its interprocess handles (hipIpcGetMemHandle /
+ * hipIpcOpenMemHandle; one process per GPU).  uncached != 0 allocates fine-grained uncached
+ * memory (required for signal blocks: peers write them while a local kernel polls).  The memory is
+ * zero-filled.  The 64-byte handle is exchanged by the caller (torch.distributed, MPI, a pipe ...). */
+SLM_API int slm_shm_alloc(void** ptr, size_t bytes, int32_t uncached);
+SLM_API int slm_shm_free(void* ptr);
+SLM_API int slm_shm_export(void* ptr, uint8_t handle[SLM_SHM_HANDLE_BYTES]);
+SLM_API int slm_shm_import(const uint8_t handle[SLM_SHM_HANDLE_BYTES], void** ptr);
+SLM_API int slm_shm_close(void* ptr);
+
+/* bytes of one rank's signal block (allocate with slm_shm_alloc(..., uncached = 1)) */
+SLM_API size_t slm_ar_signal_bytes(void);
+/* host read of a signal block's sticky error word (synchronises the device; debugging / self-test) */
+SLM_API int slm_ar_read_error(const void* own_signal, int32_t* err);
+
+typedef struct slm_ar_args {
+  int32_t rank, world;                 /* world in 2..SLM_AR_MAX_RANKS */
+  void* signals[SLM_AR_MAX_RANKS];     /* signals[r]: rank r's signal block as mapped in THIS process */
+  void* buffers[SLM_AR_MAX_RANKS];     /* buffers[r]: rank r's [M, H] T partial sums as mapped here;
+                                          buffers[rank] is local and is overwritten (own rows) */
+  void* out;                           /* [M, H] T, local: the reduced (fused: normalised) rows of
+                                          every rank; may alias buffers[rank] (in-place all-reduce) */
+  void* residual;                      /* fused: [M, H] T local residual stream, only this rank's
+                                          rows are read and updated; NULL = plain all-reduce */
+  const void* weight;                  /* fused: RMSNorm weight [H] T */
+  float eps;
+  int32_t dtype;                       /* slm_dtype */
+  int64_t M, H;                        /* H % 8 == 0, H <= 16384 */
+  int32_t end_barrier;                 /* != 0: also wait until every peer has finished reading this
+                                          rank's buffer (needed when the SAME buffer is refilled by
+                                          the next producer; alternate two buffers to avoid it) */
+  int32_t reserved;
+} slm_ar_args;
+
+SLM_API int slm_allreduce(const slm_ar_args* args, void* stream);
+/* Test hook: the work of ALL `world` ranks in one launch on one device (ranks[r] holds rank r's
+ * argument block, every pointer local).  Runs exactly the device code of slm_allreduce; lets the
+ * algorithm be verified on a single GPU. */
+SLM_API int slm_allreduce_simulate(const slm_ar_args* ranks, int32_t world, void* stream);
 
 #ifdef __cplusplus
 }

@@ -187,3 +187,14 @@ def silu_mul(x) -> np.ndarray:
     out = np.empty((x.shape[0], d), dtype=np.float32)
     lib().oracle_silu_mul(_p(x, _f32p), _p(out, _f32p), C.c_int64(x.shape[0]), C.c_int64(d))
     return out
+
+
+def allreduce_sum(partials) -> np.ndarray:
+    """SUM all-reduce: what every rank holds after ProcessGroup::allreduce
+    (src/model_parallel/process_group.cpp:135-153); the reference's own test pins it to the
+    sequential sum over ranks (process_group_test.cpp:72-77).  fp32, rank order."""
+    acc = _f32(partials[0]).copy()
+    for p in partials[1:]:
+        acc += _f32(p)
+    return acc
+

@@ -50,6 +50,18 @@ class W4GemmArgs(C.Structure):
     ]
 
 
+class ArArgs(C.Structure):
+    """struct slm_ar_args (include/slm_hip.h)."""
+    _fields_ = [
+        ("rank", C.c_int32), ("world", C.c_int32),
+        ("signals", C.c_void_p * 8), ("buffers", C.c_void_p * 8),
+        ("out", C.c_void_p), ("residual", C.c_void_p), ("weight", C.c_void_p),
+        ("eps", C.c_float), ("dtype", C.c_int32),
+        ("M", C.c_int64), ("H", C.c_int64),
+        ("end_barrier", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
 _lib = None
 
 
@@ -105,6 +117,15 @@ def lib() -> C.CDLL:
         ("slm_decode_advance", C.c_int,
          [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
           C.c_void_p, C.c_void_p]),
+        ("slm_shm_alloc", C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.c_int32]),
+        ("slm_shm_free", C.c_int, [C.c_void_p]),
+        ("slm_shm_export", C.c_int, [C.c_void_p, C.c_char_p]),
+        ("slm_shm_import", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+        ("slm_shm_close", C.c_int, [C.c_void_p]),
+        ("slm_ar_signal_bytes", C.c_size_t, []),
+        ("slm_ar_read_error", C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+        ("slm_allreduce", C.c_int, [C.POINTER(ArArgs), C.c_void_p]),
+        ("slm_allreduce_simulate", C.c_int, [C.POINTER(ArArgs), C.c_int32, C.c_void_p]),
     ]:
         fn = getattr(L, name)  # AttributeError here = library/header mismatch: fail loudly
         fn.restype = restype

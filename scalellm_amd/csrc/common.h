@@ -124,6 +124,52 @@ __device__ __forceinline__ void group_sum_many(float* v) {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// 8 x (silu(gate) * up) in fp32, rounded RN to T: THE formula of the SiLU*mul glue kernel
+// (kernel::act_and_mul, reference src/kernels/activation_kernels.cu:84), shared with the GEMM
+// prologues that fuse it so that both paths give identical bits
+template <typename T>
+__device__ __forceinline__ u32x4 silu_mul8(const u32x4 g, const u32x4 u) {
+  const float gf[8] = {lo_f32<T>(g.x), hi_f32<T>(g.x), lo_f32<T>(g.y), hi_f32<T>(g.y),
+                       lo_f32<T>(g.z), hi_f32<T>(g.z), lo_f32<T>(g.w), hi_f32<T>(g.w)};
+  const float uf[8] = {lo_f32<T>(u.x), hi_f32<T>(u.x), lo_f32<T>(u.y), hi_f32<T>(u.y),
+                       lo_f32<T>(u.z), hi_f32<T>(u.z), lo_f32<T>(u.w), hi_f32<T>(u.w)};
+  float o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float sig = __builtin_amdgcn_rcpf(1.0f + fast_exp2(-gf[j] * 1.4426950408889634f));
+    o[j] = gf[j] * sig * uf[j];
+  }
+  u32x4 r;
+  r.x = pack2<T>(o[0], o[1]); r.y = pack2<T>(o[2], o[3]);
+  r.z = pack2<T>(o[4], o[5]); r.w = pack2<T>(o[6], o[7]);
+  return r;
+}
+
+// RMSNorm row arithmetic shared by rms_norm_kernel (glue.hip) and the fused all-reduce
+// (allreduce.hip) -- normalization.h:17-52.  The fma is EXPLICIT: left to -ffp-contract the compiler
+// fuses or not per kernel, and the two paths would differ in the last bit of the sum of squares.
+__device__ __forceinline__ float rms_sumsq8(const float (&f)[8], float ss) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ss = __builtin_fmaf(f[j], f[j], ss);
+  return ss;
+}
+// y = T(T(h * rs) * w): the normalised value is rounded to T before the weight (normalization.h:27-29)
+template <typename T>
+__device__ __forceinline__ u32x4 rms_apply8(const float (&h)[8], const float rs, const u32x4 wv) {
+  const float wf[8] = {lo_f32<T>(wv.x), hi_f32<T>(wv.x), lo_f32<T>(wv.y), hi_f32<T>(wv.y),
+                       lo_f32<T>(wv.z), hi_f32<T>(wv.z), lo_f32<T>(wv.w), hi_f32<T>(wv.w)};
+  float o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float n16 = lo_f32<T>((uint32_t)pack1<T>(h[j] * rs));
+    o[j] = n16 * wf[j];
+  }
+  u32x4 r;
+  r.x = pack2<T>(o[0], o[1]); r.y = pack2<T>(o[2], o[3]);
+  r.z = pack2<T>(o[4], o[5]); r.w = pack2<T>(o[6], o[7]);
+  return r;
+}
+
 // hipGetLastError() is per-thread sticky state shared with every other HIP user in the process
 // (torch, RCCL): clear stale errors when an entry point starts, so that hip_check_launch()
 // reports only OUR launch.

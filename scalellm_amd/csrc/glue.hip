@@ -47,10 +47,8 @@ __global__ void __launch_bounds__(256) rms_norm_kernel(uint16_t* __restrict__ ou
         *reinterpret_cast<u32x4*>(residual + tok * dim + vi * 8) = w;
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        v[i][j] = f[j];
-        ss += f[j] * f[j];
-      }
+      for (int j = 0; j < 8; ++j) v[i][j] = f[j];
+      ss = rms_sumsq8(f, ss);
     }
   }
   ss = wave_sum64(ss);
@@ -63,18 +61,7 @@ __global__ void __launch_bounds__(256) rms_norm_kernel(uint16_t* __restrict__ ou
     const int64_t vi = tid + 256 * i;
     if (vi < nvec) {
       const u32x4 wv = *reinterpret_cast<const u32x4*>(weight + vi * 8);
-      const float wf[8] = {lo_f32<T>(wv.x), hi_f32<T>(wv.x), lo_f32<T>(wv.y), hi_f32<T>(wv.y),
-                           lo_f32<T>(wv.z), hi_f32<T>(wv.z), lo_f32<T>(wv.w), hi_f32<T>(wv.w)};
-      float o[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        // output.to(input) * weight: round the normalised value to T first (normalization.h:27-29)
-        const float n16 = lo_f32<T>((uint32_t)pack1<T>(v[i][j] * rs));
-        o[j] = n16 * wf[j];
-      }
-      u32x4 r;
-      r.x = pack2<T>(o[0], o[1]); r.y = pack2<T>(o[2], o[3]);
-      r.z = pack2<T>(o[4], o[5]); r.w = pack2<T>(o[6], o[7]);
+      const u32x4 r = rms_apply8<T>(v[i], rs, wv);
       *reinterpret_cast<u32x4*>(out + tok * dim + vi * 8) = r;
     }
   }
@@ -161,19 +148,7 @@ __global__ void __launch_bounds__(256) silu_mul_kernel(uint16_t* __restrict__ ou
     const int64_t t = idx / nvec, vi = idx % nvec;
     const u32x4 g = *reinterpret_cast<const u32x4*>(x + t * 2 * d + vi * 8);
     const u32x4 u = *reinterpret_cast<const u32x4*>(x + t * 2 * d + d + vi * 8);
-    const float gf[8] = {lo_f32<T>(g.x), hi_f32<T>(g.x), lo_f32<T>(g.y), hi_f32<T>(g.y),
-                         lo_f32<T>(g.z), hi_f32<T>(g.z), lo_f32<T>(g.w), hi_f32<T>(g.w)};
-    const float uf[8] = {lo_f32<T>(u.x), hi_f32<T>(u.x), lo_f32<T>(u.y), hi_f32<T>(u.y),
-                         lo_f32<T>(u.z), hi_f32<T>(u.z), lo_f32<T>(u.w), hi_f32<T>(u.w)};
-    float o[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float sig = __builtin_amdgcn_rcpf(1.0f + fast_exp2(-gf[j] * 1.4426950408889634f));
-      o[j] = gf[j] * sig * uf[j];
-    }
-    u32x4 r;
-    r.x = pack2<T>(o[0], o[1]); r.y = pack2<T>(o[2], o[3]);
-    r.z = pack2<T>(o[4], o[5]); r.w = pack2<T>(o[6], o[7]);
+    const u32x4 r = silu_mul8<T>(g, u);
     *reinterpret_cast<u32x4*>(out + t * d + vi * 8) = r;
   }
 }

@@ -87,8 +87,11 @@ class LlamaDecodeStep:
     def __init__(self, shape: LlamaShape, max_batch_tokens: int, n_blocks: int, block_size: int,
                  parallel_args: Optional[ParallelArgs] = None, quant_method: str = "awq",
                  group_size: int = 128, dtype=torch.bfloat16, device="cuda", seed: int = 0,
-                 kv_fill: str = "none"):
+                 kv_fill: str = "none", custom_allreduce=None):
         pa = parallel_args or ParallelArgs()
+        # optional custom_allreduce.XgmiAllReduce: the two row-parallel reductions of a layer then
+        # run as ONE launch each, fused with the residual add + RMSNorm that follows
+        self.custom_ar = custom_allreduce
         self.shape, self.pa, self.dtype, self.device = shape, pa, dtype, torch.device(device)
         tp = pa.world_size
         assert shape.n_heads % tp == 0 and shape.intermediate % tp == 0 and shape.hidden % tp == 0
@@ -202,23 +205,36 @@ class LlamaDecodeStep:
             from .model_parallel import gather_from_model_parallel_region
             x = gather_from_model_parallel_region(x, pa)
         resid.copy_(x)
-        delta = None
-        for L in self.layers:
-            # input RMSNorm (+ residual add of the previous block's output)
-            if delta is None:
-                kernels.rms_norm(normed, resid, L["in_norm"], s.rms_eps)
+        ar = self.custom_ar
+        if ar is not None and pa.world_size > 1:
+            o_buf, down_buf = ar.buffer(0, T), ar.buffer(1, T)
+        else:
+            o_buf, down_buf = b["o"][:T], b["down"][:T]
+
+        def reduce_add_norm(i: int, partial: torch.Tensor, weight: torch.Tensor) -> None:
+            """normed = RMSNorm(all-reduce(partial) + resid) * weight, resid updated in place
+            (reduce_from_model_parallel_region + rms_norm_residual, or the fused launch)."""
+            if ar is not None and pa.world_size > 1:
+                ar.allreduce_residual_rmsnorm(i, T, normed, resid, weight, s.rms_eps)
             else:
-                kernels.rms_norm(normed, delta, L["in_norm"], s.rms_eps, residual=resid)
+                if pa.world_size > 1:
+                    pa.process_group.allreduce(partial)
+                kernels.rms_norm(normed, partial, weight, s.rms_eps, residual=resid)
+
+        kernels.rms_norm(normed, resid, self.layers[0]["in_norm"], s.rms_eps)
+        for li, L in enumerate(self.layers):
             qkv = L["qkv"].forward(normed, out=b["qkv"][:T])
             nq, nkv = self.n_heads * D, self.n_kv_heads * D
             q, k, v = qkv[:, :nq], qkv[:, nq:nq + nkv], qkv[:, nq + nkv:]
             attn = self.attn.forward(q, k, v, positions, L["kv"], params, output=b["attn"][:T])
-            delta = L["o"].forward(attn, out=b["o"][:T])
-            kernels.rms_norm(normed, delta, L["post_norm"], s.rms_eps, residual=resid)
+            delta = L["o"].forward(attn, out=o_buf, reduce=False)
+            reduce_add_norm(0, delta, L["post_norm"])
             gu = L["gate_up"].forward(normed, out=b["gate_up"][:T])
             kernels.silu_and_mul(b["act"][:T], gu)
-            delta = L["down"].forward(b["act"][:T], out=b["down"][:T])
-        kernels.rms_norm(normed, delta, self.final_norm, s.rms_eps, residual=resid)
+            delta = L["down"].forward(b["act"][:T], out=down_buf, reduce=False)
+            # the NEXT block's input norm (or the final norm) consumes this reduction
+            nxt = self.layers[li + 1]["in_norm"] if li + 1 < len(self.layers) else self.final_norm
+            reduce_add_norm(1, delta, nxt)
         last = (params.q_cu_seq_lens[1:] - 1).long()
         logits = normed[last] @ self.lm_head  # plain library GEMM (hipBLASLt): not on the graded path
         if pa.world_size > 1:

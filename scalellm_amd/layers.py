@@ -217,7 +217,10 @@ class RowParallelQLinear(_QLinearBase):
         super().__init__(in_features, out_features, bias, quant_args, parallel_args, dtype, device)
         self.input_is_parallelized = input_is_parallelized
 
-    def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None,
+                reduce: bool = True) -> torch.Tensor:
+        """reduce=False returns this rank's PARTIAL sums (no all-reduce, no bias): the caller owns
+        the reduction (custom_allreduce.XgmiAllReduce fuses it with the residual add + RMSNorm)."""
         if self._packed is None:
             self._repack()
         if not self.input_is_parallelized and self.parallel_args.world_size > 1:
@@ -225,6 +228,10 @@ class RowParallelQLinear(_QLinearBase):
             x = scatter_to_model_parallel_region(x, self.parallel_args).contiguous()
         if self.parallel_args.world_size > 1:
             y = self._gemm(x, None, out)
+            if not reduce:
+                if self.has_bias:
+                    raise ValueError("reduce=False: the bias must be added after the reduction")
+                return y
             reduce_from_model_parallel_region(y, self.parallel_args)
             if self.has_bias:
                 y.add_(self.bias)

@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, fused_ar=False):
     try:
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                           MASTER_PORT=str(port), LOCAL_RANK="0", SLM_DIST_BACKEND="gloo")
@@ -35,10 +35,23 @@ def _worker(rank, world, port, q):
         bs, kv_len, B = 6, 70, 16
         tokens, positions, params, n_blocks = make_decode_inputs(bs, kv_len, B, dev, seed=3,
                                                                 vocab=shape.vocab)
+        ar = None
+        if fused_ar:  # the xGMI all-reduce fused with residual-add + RMSNorm
+            from scalellm_amd.custom_allreduce import try_create_xgmi_allreduce
+            ar = try_create_xgmi_allreduce(rank, world, bs, shape.hidden, torch.bfloat16, dev)
+            assert ar is not None, "fused all-reduce failed its self-test"
         tp = LlamaDecodeStep(shape, bs, n_blocks, B, pa, dtype=torch.bfloat16, device=dev, seed=5,
-                             kv_fill="consistent")
+                             kv_fill="consistent", custom_allreduce=ar)
         logits_tp = tp.forward(tokens, positions, params, return_logits=True).float().cpu()
         res = {"rank": rank, "shape": tuple(logits_tp.shape)}
+        if fused_ar:
+            # same shards, RCCL-shaped path (gloo all-reduce + slm_rms_norm): the fused launch sums
+            # in fp32 in rank order exactly like a 2-rank all-reduce, so the logits must be identical
+            plain = LlamaDecodeStep(shape, bs, n_blocks, B, pa, dtype=torch.bfloat16, device=dev, seed=5,
+                                    kv_fill="consistent")
+            logits_plain = plain.forward(tokens, positions, params, return_logits=True).float().cpu()
+            res["fused_vs_plain"] = (logits_tp - logits_plain).abs().max().item()
+            res["ar_error"] = ar.error()
         if rank == 0:
             ref = LlamaDecodeStep(shape, bs, n_blocks, B, ParallelArgs(), dtype=torch.bfloat16, device=dev,
                                   seed=5, kv_fill="consistent")
@@ -56,11 +69,12 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_tp2_matches_tp1_on_one_gpu():
+@pytest.mark.parametrize("fused_ar", [False, True])
+def test_tp2_matches_tp1_on_one_gpu(fused_ar):
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, fused_ar)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(world)]
@@ -72,3 +86,6 @@ def test_tp2_matches_tp1_on_one_gpu():
     # bf16 partial sums are rounded before the all-reduce: small, bounded drift
     assert r0["err"] <= 0.05 * r0["scale"] + 1e-3, r0
     assert r0["agree"] >= 0.8, r0
+    if fused_ar:
+        assert all(r["ar_error"] == 0 for r in res), res
+        assert all(r["fused_vs_plain"] == 0.0 for r in res), res
