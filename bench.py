@@ -230,9 +230,68 @@ def rccl_capture_works(world: int, device) -> bool:
     return bool(t.item())
 
 
+def _probe_xgmi_main():
+    """Child-process probe (bench.py --probe-xgmi-ar): can every rank map its peers' buffers and
+    does the fused xGMI all-reduce reproduce the sequential sum, eagerly and from a hipGraph?  Asked
+    in throw-away processes (own gloo group) because a wrong peer mapping would not raise -- it
+    would fault the GPU context of whoever ran it."""
+    local_rank = int(os.environ.get("SLM_FORCE_LOCAL_RANK", os.environ.get("LOCAL_RANK", "0")))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    torch.distributed.init_process_group(backend="gloo")
+    rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+    from scalellm_amd.custom_allreduce import try_create_xgmi_allreduce
+    bs, hidden = int(os.environ["SLM_PROBE_BS"]), int(os.environ["SLM_PROBE_HIDDEN"])
+    ar = try_create_xgmi_allreduce(rank, world, bs, hidden, torch.bfloat16, dev)
+    ok = ar is not None
+    if ok:  # the launch must also survive capture + replay (what the timed step does)
+        w = torch.ones(hidden, device=dev, dtype=torch.bfloat16)
+        res = torch.zeros(bs, hidden, device=dev, dtype=torch.bfloat16)
+        out = torch.empty_like(res)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in (0, 1):
+                ar.buffer(i, bs).fill_(1.0)
+                ar.allreduce_residual_rmsnorm(i, bs, out, res, w, 1e-5)
+        for _ in range(3):
+            res.zero_()
+            g.replay()
+        torch.cuda.synchronize()
+        own = ar.owned_rows(bs)
+        # after a replay: first reduction leaves residual = world, the second 2 * world, on own rows
+        ok = ar.error() == 0 and bool((res[own.start:own.stop] == 2.0 * world).all().item())
+    votes = [None] * world
+    torch.distributed.all_gather_object(votes, bool(ok))
+    if all(votes):
+        print("PROBE_XGMI_OK", flush=True)
+    os._exit(0)
+
+
+def xgmi_allreduce_works(world: int, device, bs: int, hidden: int) -> bool:
+    """All ranks: spawn the probe child, wait, and agree (MIN over ranks) on the answer."""
+    import subprocess
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + 11)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
+    env["SLM_PROBE_BS"], env["SLM_PROBE_HIDDEN"] = str(bs), str(hidden)
+    ok = 0
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-xgmi-ar"], env=env,
+                           capture_output=True, text=True, timeout=240)
+        ok = 1 if (r.returncode == 0 and "PROBE_XGMI_OK" in r.stdout) else 0
+    except Exception:  # noqa: BLE001 -- timeout or spawn failure = "no"
+        ok = 0
+    votes = [None] * world
+    torch.distributed.all_gather_object(votes, ok)
+    return all(votes)
+
+
 def main():
     if "--probe-capture" in sys.argv:
         _probe_capture_main()
+        return
+    if "--probe-xgmi-ar" in sys.argv:
+        _probe_xgmi_main()
         return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -286,10 +345,12 @@ def main():
     t_init = time.perf_counter()
     # N > 1: the two row-parallel reductions per layer run as the xGMI all-reduce fused with the
     # residual add + RMSNorm when every rank can map its peers AND the start-up
-    # self-test reproduces the sequential sum bit for bit; otherwise RCCL all-reduce + slm_rms_norm.
+    # self-test reproduces the sequential sum bit for bit (asked first in throw-away child
+    # processes, then repeated here); otherwise RCCL all-reduce + slm_rms_norm.
     # SLM_CUSTOM_AR=0 forces the RCCL path.
     custom_ar = None
-    if world > 1 and args.simulate_tp <= 1 and os.environ.get("SLM_CUSTOM_AR", "1") != "0":
+    if (world > 1 and args.simulate_tp <= 1 and os.environ.get("SLM_CUSTOM_AR", "1") != "0"
+            and xgmi_allreduce_works(world, device, bs, shape.hidden)):
         from scalellm_amd.custom_allreduce import try_create_xgmi_allreduce
         custom_ar = try_create_xgmi_allreduce(
             pg.rank, pg.world_size, bs, shape.hidden, torch.bfloat16, device,
