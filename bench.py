@@ -371,6 +371,9 @@ def main():
             kernels.decode_advance(positions, params.kv_cu_seq_lens, params.new_cache_slots,
                                    params.block_tables, params.cu_block_lens, B)
 
+    if world > 1:  # line the ranks up (model init skews them by seconds) before the first collective
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
     for _ in range(max(args.warmup, 1)):
         step()
     torch.cuda.synchronize()

@@ -258,7 +258,7 @@ SLM_API int slm_decode_advance(int32_t* positions /* [n_seqs] */, int32_t* kv_cu
 /* residual stream stays row-sharded: a rank only ever touches its own rows.  */
 /* Synchronisation: per-workgroup monotonically increasing flags in           */
 /* peer-writable UNCACHED signal blocks (no host involvement, no reset, graph */
-/* replay safe); bounded spins -- a peer that never arrives raises            */
+/* replay safe); bounded spins (20 s) -- a peer that never arrives raises     */
 /* SLM_AR_ERR_TIMEOUT in the signal block's error word instead of hanging.    */
 /* ========================================================================== */
 #define SLM_AR_MAX_RANKS 8

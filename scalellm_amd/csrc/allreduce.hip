@@ -85,7 +85,9 @@ __device__ __forceinline__ void ar_st_sys(uint16_t* ptr, const u32x4 v) {
   __hip_atomic_store(q + 1, (uint64_t)v.z | ((uint64_t)v.w << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-constexpr int AR_SPIN_LIMIT = 1 << 21;  // x ~0.5 us per poll: about a second, then give up
+// a peer that has not arrived after this long (100 MHz wall clock ticks: 20 s -- start-up skew
+// between ranks can be seconds) is presumed dead: raise the error word, do not hang the GPU
+constexpr uint64_t AR_TIMEOUT_TICKS = 20ull * 100000000ull;
 
 // Cross-rank barrier of workgroup b.  which: 0 start, 1 mid, 2 end.  All threads call it.
 // RELEASE: the caller's earlier system-scope stores must have completed (be visible to the peers)
@@ -101,13 +103,18 @@ __device__ __forceinline__ void ar_barrier(const ArParams& p, int which, int b, 
     uint32_t* dst = which == 0 ? &peer->start[b][p.rank] : which == 1 ? &peer->mid[b][p.rank] : &peer->end[b][p.rank];
     const uint32_t* src = which == 0 ? &self->start[b][t] : which == 1 ? &self->mid[b][t] : &self->end[b][t];
     __hip_atomic_store(dst, flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    int it = 0;
-    for (; it < AR_SPIN_LIMIT; ++it) {
+    const uint64_t t0 = wall_clock64();
+    bool arrived = false;
+    for (;;) {
       const uint32_t v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if ((int32_t)(v - flag) >= 0) break;
+      if ((int32_t)(v - flag) >= 0) {
+        arrived = true;
+        break;
+      }
+      if (wall_clock64() - t0 > AR_TIMEOUT_TICKS) break;
       __builtin_amdgcn_s_sleep(4);
     }
-    if (it == AR_SPIN_LIMIT)
+    if (!arrived)
       __hip_atomic_fetch_or(&self->err, (uint32_t)SLM_AR_ERR_TIMEOUT, __ATOMIC_RELAXED,
                             __HIP_MEMORY_SCOPE_SYSTEM);
   }
