@@ -36,3 +36,53 @@ def test_algorithmic_bytes_match_survey():
     assert abs(b - 4.2994e9) < 1e6
     assert abs(bench.attn_algo_bytes(32, 4096, 32, 8, 128, 16) - 537.5e6) < 1e6
     assert abs(bench.attn_algo_bytes(1, 4096, 32, 8, 128, 16) - 16.8e6) < 1e5
+
+
+def test_fused_allreduce_constructor_agrees_on_failure_without_a_gpu():
+    """try_create_xgmi_allreduce is COLLECTIVE: whatever fails locally (here: no device to allocate
+    on) every rank must make the same three control-plane exchanges and all must get None, so the
+    caller keeps the RCCL path on every rank (custom_allreduce.py)."""
+    import threading
+    from scalellm_amd.custom_allreduce import try_create_xgmi_allreduce
+    world = 2
+    rounds, lock, cv = {}, threading.Lock(), threading.Condition()
+    calls = [0] * world
+
+    def make_exchange(rank):
+        def exchange(obj):
+            idx = calls[rank]
+            calls[rank] += 1
+            with cv:
+                rounds.setdefault(idx, {})[rank] = obj
+                cv.notify_all()
+                assert cv.wait_for(lambda: len(rounds[idx]) == world, timeout=30)
+                return [rounds[idx][r] for r in range(world)]
+        return exchange
+
+    results, logs = [None] * world, []
+
+    def run(rank):
+        results[rank] = try_create_xgmi_allreduce(rank, world, 8, 64, torch.bfloat16, "cuda:0",
+                                                  exchange=make_exchange(rank), log=logs.append)
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    assert results == [None, None]
+    assert calls == [3, 3]
+    assert len(logs) == 1 and "disabled" in logs[0]
+
+
+def test_fused_allreduce_row_ownership():
+    """rows are dealt in contiguous blocks of ceil(M / world) (allreduce.hip ar_rows_of)"""
+    from scalellm_amd.custom_allreduce import XgmiAllReduce
+    ar = XgmiAllReduce.__new__(XgmiAllReduce)
+    for world, M in [(8, 256), (8, 1), (4, 7), (3, 10), (2, 5)]:
+        ar.world = world
+        seen = []
+        for r in range(world):
+            ar.rank = r
+            seen += list(ar.owned_rows(M))
+        assert seen == list(range(M))
