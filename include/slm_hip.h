@@ -276,6 +276,10 @@ SLM_API int slm_shm_free(void* ptr);
 SLM_API int slm_shm_export(void* ptr, uint8_t handle[SLM_SHM_HANDLE_BYTES]);
 SLM_API int slm_shm_import(const uint8_t handle[SLM_SHM_HANDLE_BYTES], void** ptr);
 SLM_API int slm_shm_close(void* ptr);
+/* Thread-per-GPU shape (all ranks in ONE process, the reference's: process_group.cpp:98-123): no
+ * handles -- the raw pointers are valid everywhere once `device` may access `peer_device`.  No-op
+ * (SLM_OK) when both are the same device or access is already enabled. */
+SLM_API int slm_shm_enable_peer_access(int32_t device, int32_t peer_device);
 
 /* bytes of one rank's signal block (allocate with slm_shm_alloc(..., uncached = 1)) */
 SLM_API size_t slm_ar_signal_bytes(void);

@@ -122,6 +122,7 @@ def lib() -> C.CDLL:
         ("slm_shm_export", C.c_int, [C.c_void_p, C.c_char_p]),
         ("slm_shm_import", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
         ("slm_shm_close", C.c_int, [C.c_void_p]),
+        ("slm_shm_enable_peer_access", C.c_int, [C.c_int32, C.c_int32]),
         ("slm_ar_signal_bytes", C.c_size_t, []),
         ("slm_ar_read_error", C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
         ("slm_allreduce", C.c_int, [C.POINTER(ArArgs), C.c_void_p]),

@@ -379,6 +379,24 @@ SLM_API int slm_shm_close(void* ptr) {
   return e == hipSuccess ? SLM_OK : SLM_ERR_LAUNCH;
 }
 
+SLM_API int slm_shm_enable_peer_access(int32_t device, int32_t peer_device) {
+  if (device < 0 || peer_device < 0) return SLM_ERR_INVALID_ARG;
+  if (device == peer_device) return SLM_OK;
+  int prev = 0;
+  hipError_t e = hipGetDevice(&prev);
+  if (e == hipSuccess) e = hipSetDevice(device);
+  if (e == hipSuccess) {
+    e = hipDeviceEnablePeerAccess(peer_device, 0);
+    if (e == hipErrorPeerAccessAlreadyEnabled) {
+      (void)hipGetLastError();
+      e = hipSuccess;
+    }
+    (void)hipSetDevice(prev);
+  }
+  hip_last_error_slot() = (int)e;
+  return e == hipSuccess ? SLM_OK : SLM_ERR_LAUNCH;
+}
+
 SLM_API int slm_ar_read_error(const void* own_signal, int32_t* err) {
   if (!own_signal || !err) return SLM_ERR_INVALID_ARG;
   uint32_t v = 0;

@@ -1,6 +1,11 @@
 // Python test surface of the C++ shim, modelled on the reference's scalellm/csrc/kernels.cu
 // (`_C.kernels`): lets pytest drive the C++ operator API exactly as a ScaleLLM layer would.
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/extension.h>
+
+#include <algorithm>
+#include <thread>
 
 #include "slm_torch_shim.h"
 
@@ -49,5 +54,60 @@ PYBIND11_MODULE(_slm_shim, m) {
     auto g = torch::empty({10, 10}, t.options());
     pgs[0]->allgather(t, g);
     return std::make_pair(t.sum().item<float>(), g.sum().item<float>());
+  });
+  m.def("fused_allreduce_selftest", [](int device_index, int world, int64_t n_tokens, int64_t hidden) {
+    // every rank on the SAME device, one host thread + one stream per rank (the reference drives
+    // one Worker thread per GPU, engine/worker.cpp:202-213): checks FusedAllReduce against the
+    // sequential sum -> llm::kernel::rms_norm_residual path.  Returns (max |diff| fused, max |diff|
+    // plain sum, error bits).
+    py::gil_scoped_release nogil;
+    torch::Device dev(torch::kCUDA, device_index);
+    std::vector<torch::Device> devs(world, dev);
+    auto ars = slm::FusedAllReduce::create(devs, n_tokens, hidden, torch::kBFloat16);
+    auto opt = torch::dtype(torch::kBFloat16).device(dev);
+    std::vector<torch::Tensor> parts, parts2;
+    for (int r = 0; r < world; ++r) {
+      parts.push_back(torch::randn({n_tokens, hidden}, opt));
+      parts2.push_back(torch::randn({n_tokens, hidden}, opt));
+    }
+    auto weight = torch::randn({hidden}, opt) * 0.1 + 1.0;
+    auto res0 = torch::randn({n_tokens, hidden}, opt);
+    auto sum_rn = [&](const std::vector<torch::Tensor>& ps) {
+      auto acc = ps[0].to(torch::kFloat);
+      for (int r = 1; r < world; ++r) acc = acc + ps[r].to(torch::kFloat);
+      return acc.to(torch::kBFloat16);
+    };
+    auto x1 = sum_rn(parts), x2 = sum_rn(parts2);
+    auto res_want = res0.clone();
+    auto out_want = torch::empty_like(x1);
+    llm::kernel::rms_norm_residual(out_want, res_want, x1, weight, 1e-5f);
+    torch::cuda::synchronize(device_index);
+    std::vector<double> d_fused(world, -1.0), d_sum(world, -1.0);
+    std::vector<int> errs(world, -1);
+    std::vector<std::thread> threads;
+    for (int r = 0; r < world; ++r)
+      threads.emplace_back([&, r]() {
+        c10::hip::HIPStreamGuardMasqueradingAsCUDA sg(c10::hip::getStreamFromPoolMasqueradingAsCUDA(false, device_index));
+        auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(device_index);
+        auto out = torch::empty({n_tokens, hidden}, opt);
+        auto res = res0.clone();
+        ars[r]->buffer(0, n_tokens).copy_(parts[r]);
+        ars[r]->allreduce_residual_rmsnorm(0, n_tokens, out, res, weight, 1e-5f);
+        ars[r]->buffer(1, n_tokens).copy_(parts2[r]);
+        auto s2 = ars[r]->allreduce(1, n_tokens);
+        stream.synchronize();
+        d_fused[r] = (out.to(torch::kFloat) - out_want.to(torch::kFloat)).abs().max().item<double>();
+        d_sum[r] = (s2.to(torch::kFloat) - x2.to(torch::kFloat)).abs().max().item<double>();
+        errs[r] = ars[r]->error();
+      });
+    for (auto& t : threads) t.join();
+    double mf = 0, ms = 0;
+    int e = 0;
+    for (int r = 0; r < world; ++r) {
+      mf = std::max(mf, d_fused[r]);
+      ms = std::max(ms, d_sum[r]);
+      e |= errs[r];
+    }
+    return std::make_tuple(mf, ms, e);
   });
 }

@@ -338,4 +338,113 @@ void ProcessGroupRCCL::allgather(const torch::Tensor& input,
     outputs[r].copy_(flat.narrow(0, r * input.numel(), input.numel()).view_as(outputs[r]));
 }
 
+// --------------------------------------------------------------------------------------------
+// FusedAllReduce
+// --------------------------------------------------------------------------------------------
+struct FusedAllReduce::Shared {
+  std::vector<torch::Device> devices;
+  std::vector<void*> signals;
+  std::vector<void*> buffers[2];
+  int64_t max_tokens = 0, hidden = 0;
+  torch::ScalarType dtype = torch::kBFloat16;
+  ~Shared() {
+    for (size_t r = 0; r < devices.size(); ++r) {
+      c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(devices[r]);
+      if (r < signals.size() && signals[r]) slm_shm_free(signals[r]);
+      for (auto& b : buffers)
+        if (r < b.size() && b[r]) slm_shm_free(b[r]);
+    }
+  }
+};
+
+std::vector<std::shared_ptr<FusedAllReduce>> FusedAllReduce::create(
+    const std::vector<torch::Device>& devices, int64_t max_tokens, int64_t hidden,
+    torch::ScalarType dtype) {
+  const int world = static_cast<int>(devices.size());
+  TORCH_CHECK(world >= 2 && world <= SLM_AR_MAX_RANKS, "FusedAllReduce: world size ", world);
+  TORCH_CHECK(dtype == torch::kHalf || dtype == torch::kBFloat16, "FusedAllReduce: fp16 / bf16 only");
+  auto sh = std::make_shared<Shared>();
+  sh->devices = devices;
+  sh->max_tokens = max_tokens;
+  sh->hidden = hidden;
+  sh->dtype = dtype;
+  sh->signals.assign(world, nullptr);
+  for (auto& b : sh->buffers) b.assign(world, nullptr);
+  for (int r = 0; r < world; ++r) {
+    c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(devices[r]);
+    check(slm_shm_alloc(&sh->signals[r], slm_ar_signal_bytes(), /*uncached=*/1), "slm_shm_alloc");
+    for (auto& b : sh->buffers)
+      check(slm_shm_alloc(&b[r], static_cast<size_t>(max_tokens * hidden * 2), 0), "slm_shm_alloc");
+    for (int q = 0; q < world; ++q)
+      check(slm_shm_enable_peer_access(devices[r].index(), devices[q].index()),
+                "slm_shm_enable_peer_access");
+  }
+  std::vector<std::shared_ptr<FusedAllReduce>> out;
+  for (int r = 0; r < world; ++r)
+    out.emplace_back(new FusedAllReduce(r, world, devices[r], sh));
+  return out;
+}
+
+FusedAllReduce::~FusedAllReduce() = default;
+
+torch::Tensor FusedAllReduce::buffer(int i, int64_t n_tokens) const {
+  TORCH_CHECK((i == 0 || i == 1) && n_tokens >= 1 && n_tokens <= sh_->max_tokens);
+  return torch::from_blob(sh_->buffers[i][rank_], {n_tokens, sh_->hidden},
+                          torch::dtype(sh_->dtype).device(device_));
+}
+
+namespace {
+void fill_ar_args(slm_ar_args& a, int rank, int world, const std::vector<void*>& signals,
+                  const std::vector<void*>& buffers, int64_t n_tokens, int64_t hidden,
+                  torch::ScalarType dtype) {
+  a.rank = rank;
+  a.world = world;
+  for (int r = 0; r < world; ++r) {
+    a.signals[r] = signals[r];
+    a.buffers[r] = buffers[r];
+  }
+  a.M = n_tokens;
+  a.H = hidden;
+  a.dtype = dtype == torch::kBFloat16 ? SLM_BF16 : SLM_F16;
+}
+}  // namespace
+
+torch::Tensor FusedAllReduce::allreduce(int i, int64_t n_tokens) const {
+  auto t = buffer(i, n_tokens);
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_);
+  slm_ar_args a{};
+  fill_ar_args(a, rank_, world_size_, sh_->signals, sh_->buffers[i], n_tokens, sh_->hidden, sh_->dtype);
+  a.out = t.mutable_data_ptr();
+  check(slm_allreduce(&a, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(device_.index()).stream()),
+            "slm_allreduce");
+  return t;
+}
+
+void FusedAllReduce::allreduce_residual_rmsnorm(int i, int64_t n_tokens, torch::Tensor& out,
+                                                torch::Tensor& residual, const torch::Tensor& weight,
+                                                float eps) const {
+  TORCH_CHECK(i == 0 || i == 1);
+  for (const torch::Tensor* t : {static_cast<const torch::Tensor*>(&out), static_cast<const torch::Tensor*>(&residual), &weight})
+    TORCH_CHECK(t->is_cuda() && t->is_contiguous() && t->scalar_type() == sh_->dtype,
+                "allreduce_residual_rmsnorm: contiguous device tensors of the group dtype");
+  TORCH_CHECK(out.size(0) == n_tokens && out.size(1) == sh_->hidden && residual.sizes() == out.sizes() &&
+              weight.numel() == sh_->hidden, "allreduce_residual_rmsnorm: shape mismatch");
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_);
+  slm_ar_args a{};
+  fill_ar_args(a, rank_, world_size_, sh_->signals, sh_->buffers[i], n_tokens, sh_->hidden, sh_->dtype);
+  a.out = out.mutable_data_ptr();
+  a.residual = residual.mutable_data_ptr();
+  a.weight = weight.const_data_ptr();
+  a.eps = eps;
+  check(slm_allreduce(&a, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(device_.index()).stream()),
+            "slm_allreduce");
+}
+
+int FusedAllReduce::error() const {
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_);
+  int32_t e = 0;
+  check(slm_ar_read_error(sh_->signals[rank_], &e), "slm_ar_read_error");
+  return e;
+}
+
 }  // namespace slm

@@ -114,4 +114,39 @@ class ProcessGroupRCCL {
   void* comm_;  // ncclComm_t
 };
 
+// The two row-parallel reductions of a decoder layer as ONE launch per rank each: two-shot
+// all-reduce over peer-mapped buffers fused with the residual add + RMSNorm that follows
+// (slm_allreduce, include/slm_hip.h section 6).  Replaces, at the call sites of
+// reduce_from_model_parallel_region (model_parallel.cpp:33-44) in the row-parallel linears, the
+// pair ProcessGroup::allreduce (process_group.cpp:135-153) + kernel::rms_norm_residual
+// (layernorm_kernels.cu:125).  Thread-per-GPU shape, like create_process_groups: create() is
+// called once by the engine thread, rank r's object is then used from worker thread r.
+class FusedAllReduce {
+ public:
+  static std::vector<std::shared_ptr<FusedAllReduce>> create(const std::vector<torch::Device>& devices,
+                                                             int64_t max_tokens, int64_t hidden,
+                                                             torch::ScalarType dtype);
+  ~FusedAllReduce();
+  int rank() const { return rank_; }
+  int world_size() const { return world_size_; }
+  // [n_tokens, hidden] view of this rank's message buffer i (0 / 1, alternate per call site): the
+  // row-parallel GEMM writes its partial sums here
+  torch::Tensor buffer(int i, int64_t n_tokens) const;
+  // in-place SUM over ranks of buffer i  (== ProcessGroup::allreduce on that tensor)
+  torch::Tensor allreduce(int i, int64_t n_tokens) const;
+  // out = RMSNorm(allreduce(buffer i) + residual) * weight for ALL rows; residual is updated in
+  // place on THIS rank's rows only (the residual stream stays row-sharded across ranks)
+  void allreduce_residual_rmsnorm(int i, int64_t n_tokens, torch::Tensor& out, torch::Tensor& residual,
+                                  const torch::Tensor& weight, float eps) const;
+  int error() const;  // sticky SLM_AR_ERR_* bits of this rank's signal block (synchronises)
+
+ private:
+  struct Shared;  // the allocations of every rank, freed with the last rank object
+  FusedAllReduce(int rank, int world_size, torch::Device device, std::shared_ptr<Shared> sh)
+      : rank_(rank), world_size_(world_size), device_(device), sh_(std::move(sh)) {}
+  int rank_, world_size_;
+  torch::Device device_;
+  std::shared_ptr<Shared> sh_;
+};
+
 }  // namespace slm

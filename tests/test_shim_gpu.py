@@ -109,3 +109,17 @@ def test_shim_process_group_rccl_single_gpu(shim):
     # world size = the GPUs of this box (1): RCCL comm init, collectives on the current stream
     s, g = shim.process_group_selftest(0)
     assert s == 100.0 and g == 100.0
+
+
+# world = 2 only: ranks that share ONE device need their kernels co-resident, and more than two
+# streams of one process may be multiplexed onto the same hardware queue (and then serialise);
+# larger worlds are covered by slm_allreduce_simulate (test_allreduce_gpu.py)
+@pytest.mark.parametrize("world,n_tokens,hidden", [(2, 256, 4096), (2, 37, 8192)])
+def test_shim_fused_allreduce_thread_per_rank(shim, world, n_tokens, hidden):
+    # slm::FusedAllReduce in the reference's thread-per-GPU shape (one Worker thread + stream per
+    # rank, here all on cuda:0): ProcessGroup::allreduce + kernel::rms_norm_residual
+    # (process_group.cpp:135-153, layernorm_kernels.cu:125) as one launch per rank, bit-identical
+    # to the sequential fp32 sum -> llm::kernel::rms_norm_residual
+    d_fused, d_sum, err = shim.fused_allreduce_selftest(0, world, n_tokens, hidden)
+    assert err == 0
+    assert d_fused == 0.0 and d_sum == 0.0
