@@ -528,6 +528,29 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
   pl->hgw_shift = ilog2(hgw);
   pl->nhgb = nhg / hgw;
   pl->lds_bytes = ATTN_TBL_ENT * sizeof(int) + (size_t)hgw * state;
+  // MFMA tile kernel (q_len > 1) with a long KV history and few query tiles -- speculative verify,
+  // chunked prefill: its workgroups (one per 32 / 128 query rows per KV head) are too few to hide
+  // HBM latency, so the KV range is split for it too (same partial format, same combine pass).
+  // The count is shared by every kernel of the call.  Plain prefill (kv ~ q) is never split.
+  if (a->max_q_len > 1 && forced_splits <= 0 && attn_tile_supported(D) &&
+      env_int("SLM_ATTN_TILE", 1) != 0 && a->max_kv_len >= 4 * (int64_t)a->max_q_len) {
+    const int64_t rows_max = (int64_t)a->max_q_len * G;
+    const int64_t nw_t = rows_max <= 32 ? 1 : rows_max <= 64 ? 2 : 4;
+    int64_t tiles = ((int64_t)a->n_tokens * G + 32 * nw_t - 1) / (32 * nw_t);
+    if (tiles < a->batch_size) tiles = a->batch_size;
+    const int64_t waves = tiles * a->n_kv_heads * nw_t;
+    int64_t want = env_int("SLM_ATTN_TILE_SPLITS", 0);
+    if (want <= 0) {
+      // just enough to put a wave on every SIMD: measured (tools/bench_prefill.py), splitting
+      // beyond that never pays -- with the chip full the kernel sits at its memory-system rate
+      // (~5 TB/s for 256-B rows at a 2-KiB stride) whatever the occupancy
+      want = 1024 / (waves > 0 ? waves : 1);
+      const int64_t by_len = a->max_kv_len / 512;            // >= 16 KV tiles per split
+      if (want > by_len) want = by_len;
+      if (want > 16) want = 16;
+    }
+    if (want > n_splits) n_splits = (int)want;
+  }
   if (n_splits > COMBINE_MAX_SPLITS) n_splits = COMBINE_MAX_SPLITS;
   pl->n_splits = n_splits;
   pl->u = env_int("SLM_ATTN_U", 4);
@@ -650,6 +673,14 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
   // A forced split count or an unsupported head_dim keeps everything on the token-major kernel.
   kp.rows_lo = 0;
   kp.rows_hi = 0x7fffffff;
+  if (pl.n_splits > 1) {
+    const size_t need =
+        (size_t)a->n_tokens * a->n_heads * pl.n_splits * (a->head_dim + 2) * sizeof(float);
+    if (!a->workspace || a->workspace_bytes < need) return SLM_ERR_WORKSPACE;
+    kp.o_part = reinterpret_cast<float*>(a->workspace);
+    kp.ml_part = kp.o_part + (size_t)a->n_tokens * a->n_heads * pl.n_splits * a->head_dim;
+  }
+  bool tile_used = false;
   if (a->max_q_len > 1 && a->num_splits <= 0 && attn_tile_supported(kp.head_dim) &&
       env_int("SLM_ATTN_TILE", 1) != 0) {
     hip_clear_error();
@@ -665,15 +696,9 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
       rc = launch_attn_tile(tk, a->dtype, max_rows, st);
       if (rc != SLM_OK) return rc;
     }
-    // the token-major kernel (and its split-KV combine pass) keeps the q_len = 1 sequences
+    // the token-major kernel keeps the q_len = 1 sequences
     kp.rows_hi = kp.group + 1;
-  }
-  if (pl.n_splits > 1) {
-    const size_t need =
-        (size_t)a->n_tokens * a->n_heads * pl.n_splits * (a->head_dim + 2) * sizeof(float);
-    if (!a->workspace || a->workspace_bytes < need) return SLM_ERR_WORKSPACE;
-    kp.o_part = reinterpret_cast<float*>(a->workspace);
-    kp.ml_part = kp.o_part + (size_t)a->n_tokens * a->n_heads * pl.n_splits * a->head_dim;
+    tile_used = true;
   }
   hip_clear_error();
   const int64_t grid = (int64_t)a->n_tokens * pl.nhgb * pl.n_chunks * pl.n_splits;
@@ -689,10 +714,15 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
     const dim3 g((unsigned)((items + 3) / 4)), blk(256);
     int lps_shift = 3;  // lanes per split: power of two >= head_dim / 4
     while ((4 << lps_shift) < a->head_dim) ++lps_shift;
+    AttnKParams ck = kp;
+    if (tile_used) {  // every kernel of the call wrote partials: combine every row
+      ck.rows_lo = 0;
+      ck.rows_hi = 0x7fffffff;
+    }
     if (a->dtype == SLM_BF16)
-      hipLaunchKernelGGL(attn_combine_kernel<bf16_tag>, g, blk, 0, st, kp, lps_shift);
+      hipLaunchKernelGGL(attn_combine_kernel<bf16_tag>, g, blk, 0, st, ck, lps_shift);
     else
-      hipLaunchKernelGGL(attn_combine_kernel<f16_tag>, g, blk, 0, st, kp, lps_shift);
+      hipLaunchKernelGGL(attn_combine_kernel<f16_tag>, g, blk, 0, st, ck, lps_shift);
     rc = hip_check_launch();
   }
   return rc;

@@ -16,8 +16,10 @@
 //   row max / sum are 16 register ops + one lane-half exchange -- no LDS, no 32-lane butterflies.
 //   P^T stays in registers: the C-fragment row order {4h+e, 8+4h+e} per k-step is used as the
 //   contraction order of P.V as well, so cvt_pk of the softmax outputs IS the MFMA B operand.
-//   O^T[D x 32 q] += V^T . P^T      (D/32 x 2) MFMAs; A = V^T read from a transposed LDS image
-//                                   (row stride 72 B: conflict-free ds_read_b64, two per fragment).
+//   O^T[D x 32 q] += V^T . P^T      (D/32 x 2) MFMAs; V stays ROW-major in LDS (16-B stores, as it
+//                                   arrives from HBM) and the A = V^T fragments come out of
+//                                   gfx950's transpose read: two ds_read_b64_tr_b16 per fragment,
+//                                   each handing a lane 4 consecutive kv rows of ITS d column.
 //   O accumulators have col = q row, so the online-softmax rescale is one scalar per lane.
 //
 // K/V rows are gathered through the block table (slot = table[i >> log2 bs] + (i & (bs-1)),
@@ -44,19 +46,31 @@ struct TileMfma<f16_tag> {
 };
 
 constexpr int TILE_KV = 32;
-constexpr int VT_STRIDE = 72;  // bytes per d-row of the transposed V image (32 kv * 2 B + 8 pad)
+// V tile in LDS: HD/16 sub-tiles of [32 kv][16 d] bf16 (32 B per kv row, 1 KiB per sub-tile), the
+// image ds_read_b64_tr_b16 gathers from: a 16-lane group reads a [4 kv][16 d] block (lane t points
+// at kv row t/4, 8-byte chunk t%4) and lane t receives the 4 kv values of column t.  Sub-tile s
+// sits at s * 1280 + 32 * pi(s), pi = (s >> 1) + 4 * (s & 1): the two sub-tiles a 32-lane read
+// phase touches (2m, 2m+1) land 32 banks apart and the 16 slots of a kv row a store phase writes
+// cover all 64 banks once.
+constexpr int V_SUB_STRIDE = 1280;
+__device__ __forceinline__ int v_sub_base(int s) { return s * V_SUB_STRIDE + 32 * ((s >> 1) + 4 * (s & 1)); }
+typedef short tr_v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) tr_v4s tr_lds_v4s;
 
 // NW: waves per workgroup (compile-time so the staging registers are statically indexed).
 // PF: prefetch the next K/V tile into registers while the current one is consumed.
+// waves_per_eu(2): left alone the one-wave variant takes 312 VGPRs (one wave per SIMD, and then no
+// amount of extra workgroups hides the block-table -> KV load latency chain); capped at 256 it
+// fits two without spilling.
 template <typename T, int HD, int NW, bool PF>
-__global__ void __launch_bounds__(64 * NW) attn_tile_kernel(const AttnKParams p, int tiles_per_seq) {
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) attn_tile_kernel(const AttnKParams p, int tiles_per_seq) {
   typedef typename TileMfma<T>::frag frag_t;
   constexpr int KSTEPS = HD / 16;     // MFMA k-steps of the QK product
   constexpr int DT = HD / 32;         // 32-row d-tiles of the output
   constexpr int NSLOT = HD / 8;       // 16-B slots per K row
   constexpr int K_BYTES = TILE_KV * HD * 2;
   __shared__ __attribute__((aligned(16))) char k_lds[K_BYTES];
-  __shared__ __attribute__((aligned(16))) char vt_lds[HD * VT_STRIDE];
+  __shared__ __attribute__((aligned(16))) char v_lds[(HD / 16) * V_SUB_STRIDE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -67,6 +81,8 @@ __global__ void __launch_bounds__(64 * NW) attn_tile_kernel(const AttnKParams p,
   const int l31 = lane & 31;
 
   int bid = blockIdx.x;
+  const int split = bid % p.n_splits;  // split-KV: this workgroup's share of the KV range
+  bid /= p.n_splits;
   const int tile = bid % tiles_per_seq;
   bid /= tiles_per_seq;
   const int kvh = bid % p.n_kv_heads;
@@ -109,6 +125,14 @@ __global__ void __launch_bounds__(64 * NW) attn_tile_kernel(const AttnKParams p,
   int wg_lo = 0;
   if (p.window >= 0) wg_lo = max(0, kv_len - q_len + row0 / G - p.window);
   wg_lo = (wg_lo / TILE_KV) * TILE_KV;
+  int wg_hi_s = wg_hi;
+  if (p.n_splits > 1) {
+    // equal shares in whole KV tiles; trailing splits may be empty (they publish l = 0)
+    const int n_t = (wg_hi - wg_lo + TILE_KV - 1) / TILE_KV;
+    const int per = (n_t > 0 ? (n_t + p.n_splits - 1) / p.n_splits : 0) * TILE_KV;
+    wg_lo = min(wg_lo + split * per, max(wg_hi, wg_lo));
+    wg_hi_s = min(wg_hi, wg_lo + per);
+  }
 
   f32x16 oacc[DT];
 #pragma unroll
@@ -140,28 +164,27 @@ __global__ void __launch_bounds__(64 * NW) attn_tile_kernel(const AttnKParams p,
       const int idx = tid + nthreads * i;
       const int r = idx / NSLOT, sl = idx % NSLOT;
       *reinterpret_cast<u32x4*>(k_lds + r * (HD * 2) + ((sl ^ (r & (NSLOT - 1))) << 4)) = kreg[i];
-      // V^T image: vt[d][kv r], d = 8*sl + e
-      uint16_t* vt = reinterpret_cast<uint16_t*>(vt_lds);
-      const uint32_t w[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        vt[(8 * sl + 2 * e) * (VT_STRIDE / 2) + r] = (uint16_t)(w[e] & 0xffffu);
-        vt[(8 * sl + 2 * e + 1) * (VT_STRIDE / 2) + r] = (uint16_t)(w[e] >> 16);
-      }
+      // V: row-major sub-tiles (slot sl = d / 8 -> sub-tile sl / 2, half sl % 2)
+      *reinterpret_cast<u32x4*>(v_lds + v_sub_base(sl >> 1) + r * 32 + ((sl & 1) << 4)) = vreg[i];
     }
   };
+  // transpose-read address of this lane inside a sub-tile pair: lanes 16..31 / 48..63 read the odd
+  // sub-tile (d columns 16..31 of the 32-row d tile), lane halves read kv rows +4 (hh)
+  const uint32_t v_lane = (uint32_t)(uintptr_t)v_lds +
+                          (uint32_t)(((lane & 15) >> 2) * 32 + (lane & 3) * 8 + hh * 128 +
+                                     ((lane >> 4) & 1) * (v_sub_base(1) - v_sub_base(0)));
 
   if constexpr (PF) {
-    if (wg_lo < wg_hi) {
+    if (wg_lo < wg_hi_s) {
       tile_load(wg_lo);
       tile_store();
     }
     __syncthreads();
   }
-  for (int kt0 = wg_lo; kt0 < wg_hi; kt0 += TILE_KV) {
+  for (int kt0 = wg_lo; kt0 < wg_hi_s; kt0 += TILE_KV) {
     if constexpr (PF) {
       // next tile's rows travel HBM -> registers while this tile is consumed from LDS
-      tile_load(min(kt0 + TILE_KV, wg_hi - 1));
+      tile_load(min(kt0 + TILE_KV, wg_hi_s - 1));
     } else {
       __syncthreads();  // previous tile fully consumed
       tile_load(kt0);
@@ -226,10 +249,13 @@ __global__ void __launch_bounds__(64 * NW) attn_tile_kernel(const AttnKParams p,
       const frag_t pfrag = __builtin_bit_cast(frag_t, pb);
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
-        // A[i = d row][k]: kv = 16*s2 + 4*hh + e (e < 4), 16*s2 + 8 + 4*hh + (e - 4)
-        const char* vrow = vt_lds + (d * 32 + l31) * VT_STRIDE + (16 * s2 + 4 * hh) * 2;
-        const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow);
-        const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 16);
+        // A[i = d row][k]: kv = 16*s2 + 4*hh + e (e < 4), 16*s2 + 8 + 4*hh + (e - 4): the order the
+        // softmax registers hold P in
+        // (sub-tile 2d+1 is always v_sub_base(1) - v_sub_base(0) past sub-tile 2d: folded into v_lane)
+        const uintptr_t va0 = v_lane + (uint32_t)(v_sub_base(2 * d) + (16 * s2) * 32);
+        const tr_v4s t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds_v4s*)va0);
+        const tr_v4s t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds_v4s*)(va0 + 8 * 32));
+        const u32x2 v0 = __builtin_bit_cast(u32x2, t0), v1 = __builtin_bit_cast(u32x2, t1);
         const u32x4 va = {v0.x, v0.y, v1.x, v1.y};
         oacc[d] = TileMfma<T>::run(__builtin_bit_cast(frag_t, va), pfrag, oacc[d]);
       }
@@ -243,6 +269,23 @@ __global__ void __launch_bounds__(64 * NW) attn_tile_kernel(const AttnKParams p,
 
   // ---- epilogue: O^T[d][q] / l -> out[token][head][d]; 4 consecutive d per register quad ----
   if (!jvalid) return;
+  if (p.n_splits > 1) {
+    // split-KV partials in the token-major kernel's format (combined by attn_combine_kernel):
+    // un-normalised O (fp32), running max (log2 domain) and sum of this KV share
+    const int64_t pi = ((int64_t)(q_start + tq) * p.n_heads + head) * p.n_splits + split;
+    float* opp = p.o_part + pi * HD;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4)
+        *reinterpret_cast<f32x4*>(opp + d * 32 + 8 * q4 + 4 * hh) =
+            f32x4{oacc[d][4 * q4 + 0], oacc[d][4 * q4 + 1], oacc[d][4 * q4 + 2], oacc[d][4 * q4 + 3]};
+    if (hh == 0) {
+      p.ml_part[pi * 2 + 0] = m_run;
+      p.ml_part[pi * 2 + 1] = l_run;
+    }
+    return;
+  }
   const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
   char* op = reinterpret_cast<char*>(p.out) +
              2 * ((int64_t)(q_start + tq) * p.o_ts + (int64_t)head * p.o_hs);
@@ -269,7 +312,7 @@ int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t rows, hipStream_t
   if (nw > 4) nw = 4;
   if (nw == 3) nw = 4;
   const int64_t tiles_per_seq = (rows + 32 * nw - 1) / (32 * nw);
-  const int64_t grid = tiles_per_seq * kp.n_kv_heads * kp.batch;
+  const int64_t grid = tiles_per_seq * kp.n_kv_heads * kp.batch * kp.n_splits;
   if (grid <= 0 || grid > 0x7fffffffLL) return SLM_ERR_UNSUPPORTED;
   const dim3 g((unsigned)grid), blk(64 * nw);
   const char* pfe = getenv("SLM_ATTN_TILE_PF");

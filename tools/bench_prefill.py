@@ -16,6 +16,8 @@ CASES = [  # (name, [(q_len, kv_len)] per sequence)
     ("chunk_8x256_kv4096", [(256, 4096)] * 8),
     ("specverify_120x5_kv4096", [(5, 4096)] * 120),
     ("mixed_8x256+120x5", [(256, 2048)] * 8 + [(5, 4096)] * 120),
+    ("specverify_8x5_kv4096", [(5, 4096)] * 8),
+    ("chunk_1x256_kv8192", [(256, 8192)]),
 ]
 
 
