@@ -62,7 +62,11 @@ typedef __attribute__((address_space(3))) tr_v4s tr_lds_v4s;
 // waves_per_eu(2): left alone the one-wave variant takes 312 VGPRs (one wave per SIMD, and then no
 // amount of extra workgroups hides the block-table -> KV load latency chain); capped at 256 it
 // fits two without spilling.
-template <typename T, int HD, int NW, bool PF>
+// PLAIN: no soft-cap, no alibi, no sliding window (the Llama case): KV tiles that lie entirely below
+// the causal diagonal of every row of the wave then skip the whole mask / bias arithmetic
+// (scale + max only) -- left generic, the compiler if-converts the feature tests into straight-line
+// code (16 tanh + 16 int->float + 5 compare/select per score, ~2/3 of the loop's VALU work).
+template <typename T, int HD, int NW, bool PF, bool PLAIN>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) attn_tile_kernel(const AttnKParams p, int tiles_per_seq) {
   typedef typename TileMfma<T>::frag frag_t;
   constexpr int KSTEPS = HD / 16;     // MFMA k-steps of the QK product
@@ -83,6 +87,18 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
   int bid = blockIdx.x;
   const int split = bid % p.n_splits;  // split-KV: this workgroup's share of the KV range
   bid /= p.n_splits;
+  // Causal prefill is triangular (query tile t reads (t + 1) / T of the history) and the whole grid
+  // is usually resident at once, so nothing rebalances it at run time.  Order the items so that
+  // the first half of the grid (first resident workgroup of every CU) takes the LONG query tiles
+  // in descending order and the second half (its co-resident partner) the SHORT ones ascending:
+  // every CU then holds about the same total work.
+  {
+    const int hb = p.n_kv_heads * p.batch;
+    const int n_items = tiles_per_seq * hb;
+    const int half = (n_items + 1) / 2;
+    const int r = bid < half ? bid : n_items - 1 - (bid - half);  // rank by descending query tile
+    bid = (tiles_per_seq - 1 - r / hb) + tiles_per_seq * (r % hb);
+  }
   const int tile = bid % tiles_per_seq;
   bid /= tiles_per_seq;
   const int kvh = bid % p.n_kv_heads;
@@ -207,36 +223,60 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
     // ---- scale, soft-cap, alibi, mask; online softmax for this lane's query row ----
     float sv[16];
     float mloc = -INFINITY;
+    // wave-uniform: the smallest diagonal of the wave's rows is that of its first row
+    const bool interior = PLAIN && kt0 + TILE_KV <= kv_len &&
+                          kt0 + TILE_KV - 1 <= kv_len - q_len + (row0 + wave * 32) / G;
+    if (interior) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kv_idx = kt0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      float a = sacc[r];
-      if (p.softcap > 0.f) a = fast_tanh(a * p.pre_scale);
-      a = a * p.scale_log2 + slope2 * (float)kv_idx;
-      bool vis = jvalid && kv_idx <= diag && kv_idx < kv_len;
-      if (p.window >= 0) vis = vis && (diag - kv_idx) <= p.window;
-      a = vis ? a : -INFINITY;
-      sv[r] = a;
-      mloc = fmaxf(mloc, a);
+      for (int r = 0; r < 16; ++r) {
+        sv[r] = sacc[r] * p.scale_log2;
+        mloc = fmaxf(mloc, sv[r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kv_idx = kt0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        float a = sacc[r];
+        if constexpr (!PLAIN) {
+          if (p.softcap > 0.f) a = fast_tanh(a * p.pre_scale);
+          a = a * p.scale_log2 + slope2 * (float)kv_idx;
+        } else {
+          a = a * p.scale_log2;
+        }
+        bool vis = jvalid && kv_idx <= diag && kv_idx < kv_len;
+        if constexpr (!PLAIN) {
+          if (p.window >= 0) vis = vis && (diag - kv_idx) <= p.window;
+        }
+        a = vis ? a : -INFINITY;
+        sv[r] = a;
+        mloc = fmaxf(mloc, a);
+      }
     }
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float m_new = fmaxf(m_run, mloc);
-    const float alpha = fast_exp2(m_run - m_new);
-    m_run = m_new;
-    float lsum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      sv[r] = fast_exp2(sv[r] - m_new);
-      lsum += sv[r];
-    }
-    lsum += __shfl_xor(lsum, 32, 64);
-    l_run = l_run * alpha + lsum;
-    if (__any(alpha != 1.0f)) {
+    // Lazy reference update: the running max only has to BOUND the exponents, not equal the true
+    // max -- O and l are both relative to it and it cancels in O / l.  It is advanced (and O, l
+    // rescaled: 4 * HD/32 * 16 multiplies per lane) only when some row of the wave would otherwise
+    // exceed 2^LAZY_TH; with the true max every tile the rescale ran on nearly every tile of a
+    // 2-4 k history.  P <= 2^6 keeps its full relative precision in fp16 / bf16.
+    constexpr float LAZY_TH = 6.0f;
+    if (__any(mloc > m_run + LAZY_TH)) {
+      const float m_new = fmaxf(m_run, mloc);
+      const float alpha = fast_exp2(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
 #pragma unroll
       for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
     }
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sv[r] = fast_exp2(sv[r] - m_run);
+      lsum += sv[r];
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    l_run += lsum;
 
     // ---- O^T += V^T . P^T : P fragments straight from the softmax registers ----
 #pragma unroll
@@ -317,10 +357,12 @@ int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t rows, hipStream_t
   const dim3 g((unsigned)grid), blk(64 * nw);
   const char* pfe = getenv("SLM_ATTN_TILE_PF");
   const bool pf = !(pfe && pfe[0] == '0');
+  const bool plain = kp.softcap <= 0.f && kp.alibi == nullptr && kp.window < 0;
 #define SLM_TILE(TT, HDD, NWW)                                                                    \
   do {                                                                                            \
-    if (pf) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
-    else hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, false>), g, blk, 0, st, kp, (int)tiles_per_seq); \
+    if (pf && plain) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
+    else if (pf) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, false>), g, blk, 0, st, kp, (int)tiles_per_seq); \
+    else hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, false, false>), g, blk, 0, st, kp, (int)tiles_per_seq); \
   } while (0)
 #define SLM_TILE_NW(TT, HDD)                                                                      \
   do {                                                                                            \
