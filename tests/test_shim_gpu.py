@@ -111,15 +111,29 @@ def test_shim_process_group_rccl_single_gpu(shim):
     assert s == 100.0 and g == 100.0
 
 
-# world = 2 only: ranks that share ONE device need their kernels co-resident, and more than two
-# streams of one process may be multiplexed onto the same hardware queue (and then serialise);
-# larger worlds are covered by slm_allreduce_simulate (test_allreduce_gpu.py)
+# world = 2 only, in a FRESH process: ranks that share ONE device need their kernels co-resident,
+# and streams of a process that has already created many (as this test session has) may be
+# multiplexed onto the same hardware queue and then serialise -- an artefact of testing on one GPU
+# (on N GPUs every rank has its own device and queues).  Larger worlds are covered by
+# slm_allreduce_simulate (test_allreduce_gpu.py).
 @pytest.mark.parametrize("world,n_tokens,hidden", [(2, 256, 4096), (2, 37, 8192)])
-def test_shim_fused_allreduce_thread_per_rank(shim, world, n_tokens, hidden):
+def test_shim_fused_allreduce_thread_per_rank(world, n_tokens, hidden):
     # slm::FusedAllReduce in the reference's thread-per-GPU shape (one Worker thread + stream per
     # rank, here all on cuda:0): ProcessGroup::allreduce + kernel::rms_norm_residual
     # (process_group.cpp:135-153, layernorm_kernels.cu:125) as one launch per rank, bit-identical
     # to the sequential fp32 sum -> llm::kernel::rms_norm_residual
-    d_fused, d_sum, err = shim.fused_allreduce_selftest(0, world, n_tokens, hidden)
+    import subprocess
+    import sys
+    path = os.path.join(ROOT, "scalellm_amd", "csrc", "_slm_shim.so")
+    code = (
+        "import importlib.util, torch\n"
+        f"spec = importlib.util.spec_from_file_location('_slm_shim', {path!r})\n"
+        "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+        f"print('RESULT', *m.fused_allreduce_selftest(0, {world}, {n_tokens}, {hidden}))\n")
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+    d_fused, d_sum, err = float(line[1]), float(line[2]), int(line[3])
     assert err == 0
     assert d_fused == 0.0 and d_sum == 0.0
