@@ -78,6 +78,20 @@ def test_split_kv_heuristic_host_side():
     assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(prefill)) == 1
     forced = _attn(256, 256, splits=7)
     assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(forced)) == 7
+    # MFMA tile kernel (q_len > 1): split only when the history is long against the chunk AND the
+    # tiles cannot put a wave on every SIMD; never for plain prefill (kv ~ q)
+    for k in ("SLM_ATTN_TILE", "SLM_ATTN_TILE_SPLITS"):
+        os.environ.pop(k, None)
+    one_chunk = _attn(1, 256, max_q=256, max_kv=8192)       # 8 tiles x 8 heads x 4 waves = 256 waves
+    s_chunk = L.slm_paged_kv_varlen_mha_auto_splits(C.byref(one_chunk))
+    assert s_chunk == 4
+    assert L.slm_paged_kv_varlen_mha_workspace_bytes(C.byref(one_chunk)) == 256 * 32 * s_chunk * 130 * 4
+    verify_small = _attn(8, 40, max_q=5, max_kv=4096)       # 64 one-wave tiles, 8 splits by length
+    assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(verify_small)) == 8
+    verify_big = _attn(120, 600, max_q=5, max_kv=4096)      # 960 waves: the chip is full already
+    assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(verify_big)) == 1
+    causal = _attn(1, 2048, max_q=2048, max_kv=2048)
+    assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(causal)) == 1
 
 
 @pytest.mark.parametrize("mut,code", [
