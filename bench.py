@@ -379,7 +379,9 @@ def main():
     torch.cuda.synchronize()
 
     graph = None
-    if world > 1 and torch.distributed.get_backend() != "nccl":
+    if world > 1 and custom_ar is not None:
+        pass  # the step contains no RCCL / gloo collective at all: capture it as it is
+    elif world > 1 and torch.distributed.get_backend() != "nccl":
         args.no_graph = True  # only RCCL collectives can be captured
     elif world > 1 and not args.no_graph and not rccl_capture_works(world, device):
         args.no_graph = True
@@ -468,7 +470,9 @@ def main():
                        "parallelism": f"tp{world}" if world > 1 else "single-gpu",
                        "hip_graph": graph is not None, "reduced_model": reduced,
                        "row_parallel_reduce": (None if world == 1 else
-                                               "xgmi two-shot all-reduce fused with residual+rmsnorm"
+                                               "xgmi two-shot all-reduce fused with residual+rmsnorm "
+                                               "(embedding gather and greedy sampling exchange through "
+                                               "the same kernel: no RCCL in the step)"
                                                if custom_ar is not None else "rccl all-reduce + rms_norm"),
                        "device_side_input_advance": bool(args.advance),
                        "simulated_tp_rank0_only": args.simulate_tp if args.simulate_tp > 1 else None,

@@ -200,21 +200,31 @@ class LlamaDecodeStep:
         T = tokens.numel()
         D = s.head_dim
         resid, normed = b["resid"][:T], b["normed"][:T]
+        ar = self.custom_ar if pa.world_size > 1 else None
         x = self.embed[tokens.long()]
-        if pa.world_size > 1:
-            from .model_parallel import gather_from_model_parallel_region
-            x = gather_from_model_parallel_region(x, pa)
-        resid.copy_(x)
-        ar = self.custom_ar
-        if ar is not None and pa.world_size > 1:
+        if ar is not None:
+            # hidden-sharded embedding gather (embedding.h:74-81) as a SUM of disjoint column
+            # slices through the fused all-reduce's plain mode: exact, and keeps the captured step
+            # free of RCCL.  Message buffers alternate strictly over the step:
+            # embedding 1, then (o_proj 0, down_proj 1) per layer, then the sampling exchange 0.
+            Hs = s.hidden // pa.world_size
+            ebuf = ar.buffer(1, T)
+            ebuf.zero_()
+            ebuf[:, pa.rank * Hs:(pa.rank + 1) * Hs] = x
+            ar.allreduce(1, T)
+            resid.copy_(ebuf)
             o_buf, down_buf = ar.buffer(0, T), ar.buffer(1, T)
         else:
+            if pa.world_size > 1:
+                from .model_parallel import gather_from_model_parallel_region
+                x = gather_from_model_parallel_region(x, pa)
+            resid.copy_(x)
             o_buf, down_buf = b["o"][:T], b["down"][:T]
 
         def reduce_add_norm(i: int, partial: torch.Tensor, weight: torch.Tensor) -> None:
             """normed = RMSNorm(all-reduce(partial) + resid) * weight, resid updated in place
             (reduce_from_model_parallel_region + rms_norm_residual, or the fused launch)."""
-            if ar is not None and pa.world_size > 1:
+            if ar is not None:
                 ar.allreduce_residual_rmsnorm(i, T, normed, resid, weight, s.rms_eps)
             else:
                 if pa.world_size > 1:
@@ -237,12 +247,39 @@ class LlamaDecodeStep:
             reduce_add_norm(1, delta, nxt)
         last = (params.q_cu_seq_lens[1:] - 1).long()
         logits = normed[last] @ self.lm_head  # plain library GEMM (hipBLASLt): not on the graded path
+        if ar is not None and not return_logits and last.numel() <= ar.max_tokens \
+                and 4 * pa.world_size <= s.hidden:
+            return self._greedy_over_vocab_shards(logits, ar)
         if pa.world_size > 1:
             from .model_parallel import gather_from_model_parallel_region
             logits = gather_from_model_parallel_region(logits, pa)
         if return_logits:
             return logits
         return torch.argmax(logits.float(), dim=-1).to(torch.int32)
+
+
+    def _greedy_over_vocab_shards(self, logits: torch.Tensor, ar) -> torch.Tensor:
+        """argmax over the vocab-sharded logits without gathering them (and without RCCL): every
+        rank publishes (its maximum, the local index as three base-128 digits) -- all exactly
+        representable in the 16-bit dtype -- in its own four columns of a zero message, the plain
+        all-reduce sums the disjoint entries, and every rank picks the best shard.  Same result as
+        argmax over gather_from_model_parallel_region(logits): ties go to the lowest index."""
+        pa = self.pa
+        n, vs = logits.shape
+        val, idx = logits.max(dim=-1)            # first maximum inside the shard
+        msg = ar.buffer(0, n)
+        msg.zero_()
+        c = 4 * pa.rank
+        msg[:, c] = val
+        msg[:, c + 1] = (idx >> 14).to(msg.dtype)
+        msg[:, c + 2] = ((idx >> 7) & 127).to(msg.dtype)
+        msg[:, c + 3] = (idx & 127).to(msg.dtype)
+        ar.allreduce(0, n)
+        allv = msg[:, :4 * pa.world_size].float().view(n, pa.world_size, 4)
+        best = allv[:, :, 0].argmax(dim=-1)      # first shard holding the global maximum
+        d = allv[torch.arange(n, device=logits.device), best].long()
+        local = (d[:, 1] << 14) + (d[:, 2] << 7) + d[:, 3]
+        return (best * vs + local).to(torch.int32)
 
 
 def make_decode_inputs(batch: int, kv_len: int, block_size: int, device, seed: int = 0,

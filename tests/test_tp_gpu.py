@@ -51,6 +51,10 @@ def _worker(rank, world, port, q, fused_ar=False):
                                     kv_fill="consistent")
             logits_plain = plain.forward(tokens, positions, params, return_logits=True).float().cpu()
             res["fused_vs_plain"] = (logits_tp - logits_plain).abs().max().item()
+            # greedy path: embedding gather + vocab-sharded argmax through the same kernel (no
+            # gloo / RCCL collective in the step) == argmax over the gathered logits
+            toks = tp.forward(tokens, positions, params).cpu()
+            res["greedy_ok"] = bool((toks == logits_tp.argmax(-1).to(torch.int32)).all().item())
             res["ar_error"] = ar.error()
         if rank == 0:
             ref = LlamaDecodeStep(shape, bs, n_blocks, B, ParallelArgs(), dtype=torch.bfloat16, device=dev,
@@ -89,3 +93,4 @@ def test_tp2_matches_tp1_on_one_gpu(fused_ar):
     if fused_ar:
         assert all(r["ar_error"] == 0 for r in res), res
         assert all(r["fused_vs_plain"] == 0.0 for r in res), res
+        assert all(r["greedy_ok"] for r in res), res
