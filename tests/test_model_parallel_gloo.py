@@ -61,6 +61,34 @@ def _worker(rank, world, port, q):
         assert torch.equal(xs, X[:, rank * 8:(rank + 1) * 8])
         row = reduce_from_model_parallel_region((xs @ W[rank * 8:(rank + 1) * 8]).contiguous(), pa)
         assert torch.allclose(row, ref, atol=1e-5)
+        # greedy sampling over vocab shards (decode.py): (shard max, local index as base-128 digits)
+        # summed as disjoint message columns == argmax over the gathered logits, ties to the lowest
+        # index -- with a gloo stand-in for the fused all-reduce's buffer / plain all-reduce
+        from scalellm_amd.decode import LlamaDecodeStep
+
+        class _GlooAR:
+            max_tokens = 16
+
+            def __init__(self):
+                self.buf = [torch.zeros(16, 64, dtype=torch.bfloat16) for _ in range(2)]
+
+            def buffer(self, i, n):
+                return self.buf[i][:n]
+
+            def allreduce(self, i, n):
+                t = self.buf[i][:n].clone()
+                pg.allreduce(t)
+                self.buf[i][:n].copy_(t)
+
+        step = LlamaDecodeStep.__new__(LlamaDecodeStep)
+        step.pa = pa
+        for vs in (300, 20000):  # 20000 > 2^14: exercises the third index digit
+            full = torch.randn(9, world * vs, generator=g).bfloat16()
+            full[0, 5] = full[0, vs + 100] = 100.0        # tie across shards -> index 5
+            full[1, vs + 10] = full[1, vs + 20] = 50.0    # tie inside shard 1 -> the first
+            full[2, world * vs - 1] = 77.0                # very last entry of the last shard
+            got = step._greedy_over_vocab_shards(full[:, rank * vs:(rank + 1) * vs].contiguous(), _GlooAR())
+            assert torch.equal(got, full.float().argmax(-1).to(torch.int32)), (vs, got)
         pg.barrier()
         torch.distributed.destroy_process_group()
         q.put((rank, "ok"))
