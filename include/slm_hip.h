@@ -294,7 +294,10 @@ typedef struct slm_ar_args {
   void* out;                           /* [M, H] T, local: the reduced (fused: normalised) rows of
                                           every rank; may alias buffers[rank] (in-place all-reduce) */
   void* residual;                      /* fused: [M, H] T local residual stream, only this rank's
-                                          rows are read and updated; NULL = plain all-reduce */
+                                          rows are read and updated (ALL rows in one-shot mode:
+                                          M <= world and out != buffers[rank], where every rank
+                                          reduces every row itself behind a single barrier);
+                                          NULL = plain all-reduce */
   const void* weight;                  /* fused: RMSNorm weight [H] T */
   float eps;
   int32_t dtype;                       /* slm_dtype */

@@ -17,6 +17,8 @@
 //   mid barrier     release (L2 write-back) -> flags -> acquire (invalidate)
 //   stage 2         gather the rows of the other ranks from THEIR buffers into `out`
 //   (end barrier)   optional; callers alternate two buffers instead (see slm_hip.h)
+//   one-shot        M <= world (and `out` is not the message buffer): start barrier, then every rank
+//                   reduces ALL rows itself -- no publish, no mid barrier, no gather
 // Workgroup b only ever depends on workgroup b of the peers (it produces rows b, b + nb, ... of its
 // rank's share and consumes the same rows of the others), so the barriers are per workgroup:
 // flags[b][rank] in the PEER's signal block, written with system-scope stores, polled locally.
@@ -60,6 +62,7 @@ struct ArParams {
   int64_t M, H;
   int rpr;  // rows per rank = ceil(M / world)
   int end_barrier;
+  int one_shot;  // M <= world and out is not the message buffer: every rank reduces EVERY row
 };
 
 struct ArSimParams {
@@ -142,10 +145,14 @@ __device__ __forceinline__ void ar_body(const ArParams& p, const int b, const in
 
   ar_barrier<false>(p, 0, b, flag);
 
-  // ---- stage 1: reduce (and normalise) this rank's rows ----
-  const int my_rows = ar_rows_of(p, p.rank);
+  // ---- stage 1: reduce (and normalise) this rank's rows.  One-shot mode (at most one row per
+  // rank): every rank reduces ALL rows itself straight into `out` -- redundant work on a few rows
+  // instead of a second flag barrier and a gather; nothing is published, the peers' reads of this
+  // rank's buffer go on undisturbed ----
+  const int my_rows = p.one_shot ? (int)p.M : ar_rows_of(p, p.rank);
+  const int64_t row_base = p.one_shot ? 0 : (int64_t)p.rank * p.rpr;
   for (int row = b; row < my_rows; row += nb) {
-    const int64_t off = ((int64_t)p.rank * p.rpr + row) * H;
+    const int64_t off = (row_base + row) * H;
     float v[MAXV][8];
     float ss = 0.f;
 #pragma unroll
@@ -183,7 +190,7 @@ __device__ __forceinline__ void ar_body(const ArParams& p, const int b, const in
         x.x = pack2<T>(f[0], f[1]); x.y = pack2<T>(f[2], f[3]);
         x.z = pack2<T>(f[4], f[5]); x.w = pack2<T>(f[6], f[7]);
         if constexpr (!FUSED) {
-          ar_st_sys(p.buf[p.rank] + off + vi * 8, x);
+          if (!p.one_shot) ar_st_sys(p.buf[p.rank] + off + vi * 8, x);
           if (p.out != p.buf[p.rank]) *reinterpret_cast<u32x4*>(p.out + off + vi * 8) = x;
         } else {
           // h = x + residual (fp32), residual = T(h): normalization.h:42-52
@@ -214,7 +221,7 @@ __device__ __forceinline__ void ar_body(const ArParams& p, const int b, const in
         if (vi < nvec) {
           const u32x4 wv = *reinterpret_cast<const u32x4*>(p.weight + vi * 8);
           const u32x4 y = rms_apply8<T>(v[i], rs, wv);
-          ar_st_sys(p.buf[p.rank] + off + vi * 8, y);
+          if (!p.one_shot) ar_st_sys(p.buf[p.rank] + off + vi * 8, y);
           if (p.out != p.buf[p.rank]) *reinterpret_cast<u32x4*>(p.out + off + vi * 8) = y;
         }
       }
@@ -222,6 +229,12 @@ __device__ __forceinline__ void ar_body(const ArParams& p, const int b, const in
     }
   }
 
+  if (p.one_shot) {
+    if (p.end_barrier) ar_barrier<false>(p, 2, b, flag);
+    if (tid == 0)
+      __hip_atomic_store(&self->counter[b], flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   ar_barrier<true>(p, 1, b, flag);
 
   // ---- stage 2: gather the other ranks' rows (peer order rotated so that the 7 links of a rank
@@ -302,6 +315,7 @@ static int ar_fill(const slm_ar_args* a, ArParams* p) {
   p->H = a->H;
   p->rpr = (int)((a->M + a->world - 1) / a->world);
   p->end_barrier = a->end_barrier;
+  p->one_shot = (a->M <= a->world && a->out != a->buffers[a->rank]) ? 1 : 0;
   return SLM_OK;
 }
 
@@ -413,7 +427,8 @@ SLM_API int slm_allreduce(const slm_ar_args* a, void* stream) {
   const int rc = ar_fill(a, &p);
   if (rc != SLM_OK) return rc;
   hip_clear_error();
-  const int nb = p.rpr < SLM_AR_MAX_BLOCKS ? p.rpr : SLM_AR_MAX_BLOCKS;
+  const int rows = p.one_shot ? (int)p.M : p.rpr;  // rows a rank reduces: one workgroup each
+  const int nb = rows < SLM_AR_MAX_BLOCKS ? rows : SLM_AR_MAX_BLOCKS;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   ar_dispatch(a->dtype, a->residual != nullptr, a->world, [&](auto t, auto f, auto w) {
     using TT = decltype(t);
@@ -437,7 +452,9 @@ SLM_API int slm_allreduce_simulate(const slm_ar_args* ranks, int32_t world, void
   hip_clear_error();
   // every workgroup of every rank must be resident at once (they wait for each other): at most one
   // workgroup per CU
-  int nb = sp.r[0].rpr;
+  for (int r = 1; r < world; ++r)
+    if (sp.r[r].one_shot != sp.r[0].one_shot) return SLM_ERR_INVALID_ARG;  // every rank, one mode
+  int nb = sp.r[0].one_shot ? (int)sp.r[0].M : sp.r[0].rpr;
   const int cap = 256 / world < SLM_AR_MAX_BLOCKS ? 256 / world : SLM_AR_MAX_BLOCKS;
   if (nb > cap) nb = cap;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
