@@ -177,12 +177,21 @@ typedef struct slm_w4_gemm_args {
   int64_t lda, ldc;
   int64_t group_size;   /* K for per-channel (-1 in the checkpoint)           */
   int32_t dtype;
-  int32_t reserved;
+  int32_t flags;        /* SLM_W4_* bits, 0 = none                            */
   void* workspace;      /* split-K partials + act-order A copy                */
   size_t workspace_bytes;
 } slm_w4_gemm_args;
 
+/* flags: leave a split-K GEMM's fp32 partial sums [splits][M][N] at the START of `workspace`
+ * instead of reducing them into c (which is then NOT written): the consumer absorbs the sum --
+ * slm_rms_norm_splitk does, removing one launch and one round trip of the activations per
+ * row-parallel linear.  Ignored (normal reduce) when bias != NULL.  Whether a given call defers is
+ * a pure function of the argument block: ask slm_w4a16_gemm_deferred_splits first. */
+#define SLM_W4_DEFER_REDUCE 1
+
 SLM_API size_t slm_w4a16_gemm_workspace_bytes(const slm_w4_gemm_args* a);
+/* number of partial slabs the call will leave in the workspace (>= 2), or 0 when it writes c as usual */
+SLM_API int32_t slm_w4a16_gemm_deferred_splits(const slm_w4_gemm_args* a);
 SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream);
 
 /* Slow dequantise-to-dense helper (debug / parity): w_out [K, N] T.          */
@@ -201,6 +210,12 @@ SLM_API int slm_w4_dequant(const void* wq, const void* sz, int64_t K, int64_t N,
  * (rms_norm_residual, src/layers/normalization.h:42-52). */
 SLM_API int slm_rms_norm(void* out, const void* x, const void* weight, void* residual,
                          int64_t n_tokens, int64_t dim, float eps, int32_t dtype, void* stream);
+/* The same with x given as the split-K partial sums a deferred GEMM left behind
+ * (SLM_W4_DEFER_REDUCE): x := T(sum_s partials[s][t][:]) in the reduce kernel's own order, so the
+ * result is bit-identical to "reduce, then slm_rms_norm". */
+SLM_API int slm_rms_norm_splitk(void* out, const float* partials /* [n_splits, n_tokens, dim] */,
+                                int32_t n_splits, const void* weight, void* residual,
+                                int64_t n_tokens, int64_t dim, float eps, int32_t dtype, void* stream);
 /* Rotary embedding applied in place to q and k, fused with the KV append that always follows it
  * (src/layers/attention/attention.cpp:36-42).  cos_sin row = [cos(rot/2) | sin(rot/2)] per
  * position (the reference cache layout, pos_embedding_kernels.cu:41: [max_pos, 2, rot/2]), either

@@ -45,9 +45,12 @@ class W4GemmArgs(C.Structure):
         ("bias", C.c_void_p), ("c", C.c_void_p),
         ("M", C.c_int64), ("K", C.c_int64), ("N", C.c_int64),
         ("lda", C.c_int64), ("ldc", C.c_int64), ("group_size", C.c_int64),
-        ("dtype", C.c_int32), ("reserved", C.c_int32),
+        ("dtype", C.c_int32), ("flags", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
+
+
+SLM_W4_DEFER_REDUCE = 1
 
 
 class ArArgs(C.Structure):
@@ -102,6 +105,10 @@ def lib() -> C.CDLL:
           C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
         ("slm_w4a16_gemm_workspace_bytes", C.c_size_t, [C.POINTER(W4GemmArgs)]),
         ("slm_w4a16_gemm", C.c_int, [C.POINTER(W4GemmArgs), C.c_void_p]),
+        ("slm_w4a16_gemm_deferred_splits", C.c_int32, [C.POINTER(W4GemmArgs)]),
+        ("slm_rms_norm_splitk", C.c_int,
+         [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float,
+          C.c_int32, C.c_void_p]),
         ("slm_w4_dequant", C.c_int,
          [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
           C.c_void_p]),

@@ -145,6 +145,29 @@ __device__ __forceinline__ u32x4 silu_mul8(const u32x4 g, const u32x4 u) {
   return r;
 }
 
+// sum over split-K partial slabs of 4 consecutive columns, in THE order of the split-K reduce
+// kernel (w4.hip) -- shared with the RMSNorm that can absorb the reduction (glue.hip), so that
+// "GEMM -> reduce -> norm" and "GEMM (deferred) -> norm" give identical bits
+__device__ __forceinline__ f32x4 splitk_sum4(const float* __restrict__ src, const int64_t slab,
+                                             const int split_k) {
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= split_k; k += 8) {  // 8 independent 16-B loads in flight per thread
+    f32x4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + (k + i) * slab);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+  }
+  for (; k + 2 <= split_k; k += 2) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + k * slab);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(src + (k + 1) * slab);
+    s += a + b;
+  }
+  if (k < split_k) s += *reinterpret_cast<const f32x4*>(src + k * slab);
+  return s;
+}
+
 // RMSNorm row arithmetic shared by rms_norm_kernel (glue.hip) and the fused all-reduce
 // (allreduce.hip) -- normalization.h:17-52.  The fma is EXPLICIT: left to -ffp-contract the compiler
 // fuses or not per kernel, and the two paths would differ in the last bit of the sum of squares.

@@ -22,7 +22,8 @@ __global__ void __launch_bounds__(256) rms_norm_kernel(uint16_t* __restrict__ ou
                                                        const uint16_t* __restrict__ x,
                                                        const uint16_t* __restrict__ weight,
                                                        uint16_t* __restrict__ residual, int64_t dim,
-                                                       float eps) {
+                                                       float eps, const float* __restrict__ part,
+                                                       int n_splits, int64_t slab) {
   __shared__ float red[4];
   const int64_t tok = blockIdx.x;
   const int tid = threadIdx.x;
@@ -34,7 +35,15 @@ __global__ void __launch_bounds__(256) rms_norm_kernel(uint16_t* __restrict__ ou
   for (int i = 0; i < MAXV; ++i) {
     const int64_t vi = tid + 256 * i;
     if (vi < nvec) {
-      u32x4 a = *reinterpret_cast<const u32x4*>(x + tok * dim + vi * 8);
+      u32x4 a;
+      if (part) {  // x = T(sum of the split-K partial slabs): what the reduce kernel would have left
+        const f32x4 s0 = splitk_sum4(part + tok * dim + vi * 8, slab, n_splits);
+        const f32x4 s1 = splitk_sum4(part + tok * dim + vi * 8 + 4, slab, n_splits);
+        a.x = pack2<T>(s0.x, s0.y); a.y = pack2<T>(s0.z, s0.w);
+        a.z = pack2<T>(s1.x, s1.y); a.w = pack2<T>(s1.z, s1.w);
+      } else {
+        a = *reinterpret_cast<const u32x4*>(x + tok * dim + vi * 8);
+      }
       float f[8] = {lo_f32<T>(a.x), hi_f32<T>(a.x), lo_f32<T>(a.y), hi_f32<T>(a.y),
                     lo_f32<T>(a.z), hi_f32<T>(a.z), lo_f32<T>(a.w), hi_f32<T>(a.w)};
       if (residual) {  // x = input + residual (fp32), residual = T(x): normalization.h:42-52
@@ -159,25 +168,45 @@ using namespace slm;
 
 extern "C" {
 
-SLM_API int slm_rms_norm(void* out, const void* x, const void* weight, void* residual,
-                         int64_t n_tokens, int64_t dim, float eps, int32_t dtype, void* stream) {
+static int rms_norm_launch(void* out, const void* x, const float* part, int32_t n_splits,
+                           const void* weight, void* residual, int64_t n_tokens, int64_t dim,
+                           float eps, int32_t dtype, void* stream) {
   if (n_tokens == 0) return SLM_OK;
-  if (!out || !x || !weight || n_tokens < 0) return SLM_ERR_INVALID_ARG;
+  if (!out || (!x && !part) || !weight || n_tokens < 0) return SLM_ERR_INVALID_ARG;
+  if (part && n_splits < 1) return SLM_ERR_INVALID_ARG;
   if (dim <= 0 || dim % 8 || dim > 16384) return SLM_ERR_UNSUPPORTED;
-  if (!aligned16(out) || !aligned16(x) || !aligned16(weight) || (residual && !aligned16(residual)))
+  if (!aligned16(out) || (x && !aligned16(x)) || (part && !aligned16(part)) || !aligned16(weight) ||
+      (residual && !aligned16(residual)))
     return SLM_ERR_ALIGNMENT;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hip_clear_error();
   const dim3 grid((unsigned)n_tokens), blk(256);
+  const int64_t slab = n_tokens * dim;
   if (dtype == SLM_BF16)
     hipLaunchKernelGGL(rms_norm_kernel<bf16_tag>, grid, blk, 0, st, (uint16_t*)out,
-                       (const uint16_t*)x, (const uint16_t*)weight, (uint16_t*)residual, dim, eps);
+                       (const uint16_t*)x, (const uint16_t*)weight, (uint16_t*)residual, dim, eps,
+                       part, (int)n_splits, slab);
   else if (dtype == SLM_F16)
     hipLaunchKernelGGL(rms_norm_kernel<f16_tag>, grid, blk, 0, st, (uint16_t*)out,
-                       (const uint16_t*)x, (const uint16_t*)weight, (uint16_t*)residual, dim, eps);
+                       (const uint16_t*)x, (const uint16_t*)weight, (uint16_t*)residual, dim, eps,
+                       part, (int)n_splits, slab);
   else
     return SLM_ERR_UNSUPPORTED;
   return hip_check_launch();
+}
+
+SLM_API int slm_rms_norm(void* out, const void* x, const void* weight, void* residual,
+                         int64_t n_tokens, int64_t dim, float eps, int32_t dtype, void* stream) {
+  if (n_tokens != 0 && !x) return SLM_ERR_INVALID_ARG;
+  return rms_norm_launch(out, x, nullptr, 0, weight, residual, n_tokens, dim, eps, dtype, stream);
+}
+
+SLM_API int slm_rms_norm_splitk(void* out, const float* partials, int32_t n_splits, const void* weight,
+                                void* residual, int64_t n_tokens, int64_t dim, float eps,
+                                int32_t dtype, void* stream) {
+  if (n_tokens != 0 && !partials) return SLM_ERR_INVALID_ARG;
+  return rms_norm_launch(out, nullptr, partials, n_splits, weight, residual, n_tokens, dim, eps, dtype,
+                         stream);
 }
 
 SLM_API int slm_rope_kv_append(void* q, int64_t q_token_stride, void* k, int64_t k_token_stride,

@@ -410,23 +410,7 @@ __global__ void __launch_bounds__(256) w4_splitk_reduce_kernel(const float* __re
   const int64_t idx4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // 4 columns per thread
   if (idx4 * 4 >= M * N) return;
   const int64_t m = (idx4 * 4) / N, n = (idx4 * 4) % N;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  const float* src = part + m * N + n;
-  const int64_t slab = M * N;
-  int k = 0;
-  for (; k + 8 <= split_k; k += 8) {  // 8 independent 16-B loads in flight per thread
-    f32x4 v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + (k + i) * slab);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s += v[i];
-  }
-  for (; k + 2 <= split_k; k += 2) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(src + k * slab);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(src + (k + 1) * slab);
-    s += a + b;
-  }
-  if (k < split_k) s += *reinterpret_cast<const f32x4*>(src + k * slab);
+  f32x4 s = splitk_sum4(part + m * N + n, M * N, split_k);
   if (bias) {
     const u32x2 b = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(bias) + n);
     s.x += lo_f32<T>(b.x); s.y += hi_f32<T>(b.x);
@@ -653,6 +637,12 @@ SLM_API size_t slm_w4a16_gemm_workspace_bytes(const slm_w4_gemm_args* a) {
   return pl.part_bytes + pl.aperm_bytes;
 }
 
+SLM_API int32_t slm_w4a16_gemm_deferred_splits(const slm_w4_gemm_args* a) {
+  GemmPlan pl;
+  if (plan_gemm(a, &pl) != SLM_OK) return 0;
+  return (a->flags & SLM_W4_DEFER_REDUCE) && !a->bias && pl.split_k > 1 ? pl.split_k : 0;
+}
+
 SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream) {
   GemmPlan pl;
   int rc = plan_gemm(a, &pl);
@@ -700,7 +690,7 @@ SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream) {
   else launch_gemm<f16_tag>(kp, pl, st);
   rc = hip_check_launch();
   if (rc != SLM_OK) return rc;
-  if (pl.split_k > 1) {
+  if (pl.split_k > 1 && !((a->flags & SLM_W4_DEFER_REDUCE) && !a->bias)) {
     const int64_t n4 = a->M * a->N / 4;
     const dim3 grid((unsigned)((n4 + 255) / 256)), blk(256);
     if (a->dtype == SLM_BF16)

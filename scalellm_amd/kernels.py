@@ -301,19 +301,27 @@ def _gemm_args(a, packed: PackedW4, c, bias) -> W4GemmArgs:
 
 
 def gptq_gemm(a: torch.Tensor, packed: PackedW4, c: torch.Tensor,
-              bias: Optional[torch.Tensor] = None) -> None:
+              bias: Optional[torch.Tensor] = None, defer_reduce: bool = False) -> int:
     """Mirror of marlin::gptq_gemm (marlin.h:17-25): C[M,N] = A[M,K] . dequant(W) (+ bias),
     fp32 accumulate, written into the pre-allocated `c`.  AWQ and GPTQ share it, as in the
-    reference (has_zp true/false): zero points live in the prepacked scale/zero table."""
+    reference (has_zp true/false): zero points live in the prepacked scale/zero table.
+
+    defer_reduce: when the call is split over K, leave the fp32 partial sums in the device
+    workspace for the consumer (rms_norm(..., partial_splits=n)) instead of reducing them into
+    `c`.  Returns the number of partial slabs left behind (>= 2), or 0 when `c` was written."""
     L = _lib.lib()
     g = _gemm_args(a, packed, c, bias)
     if g.M == 0:
-        return
+        return 0
+    if defer_reduce:
+        g.flags = _lib.SLM_W4_DEFER_REDUCE
     need = L.slm_w4a16_gemm_workspace_bytes(C.byref(g))
     if need:
         ws = reserve_workspace(need, a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
+    deferred = L.slm_w4a16_gemm_deferred_splits(C.byref(g)) if defer_reduce else 0
     check(L.slm_w4a16_gemm(C.byref(g), _stream()), "slm_w4a16_gemm")
+    return deferred
 
 
 def w4_dequant(packed: PackedW4) -> torch.Tensor:
@@ -330,8 +338,12 @@ def w4_dequant(packed: PackedW4) -> torch.Tensor:
 # glue ops (next rows f1/f2)
 # ---------------------------------------------------------------------------------------
 def rms_norm(out: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, eps: float,
-             residual: Optional[torch.Tensor] = None) -> None:
-    """kernel::rms_norm / rms_norm_residual (layernorm_kernels.cu:15,125)."""
+             residual: Optional[torch.Tensor] = None, partial_splits: int = 0) -> None:
+    """kernel::rms_norm / rms_norm_residual (layernorm_kernels.cu:15,125).
+
+    partial_splits > 0: `x` was NOT written -- a gptq_gemm(..., defer_reduce=True) left that many
+    fp32 split-K slabs [splits, tokens, dim] at the start of the device workspace; the norm sums them
+    itself (same order and rounding as the reduce kernel: identical bits, one launch less)."""
     L = _lib.lib()
     _require_gpu(out, x, weight, residual)
     if not (x.is_contiguous() and out.is_contiguous() and weight.is_contiguous()):
@@ -339,8 +351,14 @@ def rms_norm(out: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, eps: floa
     if residual is not None and not residual.is_contiguous():
         raise SlmError("rms_norm needs a contiguous residual")
     dim = x.size(-1)
-    check(L.slm_rms_norm(out.data_ptr(), x.data_ptr(), weight.data_ptr(),
-                         residual.data_ptr() if residual is not None else None,
+    res_ptr = residual.data_ptr() if residual is not None else None
+    if partial_splits > 0:
+        ws = reserve_workspace(partial_splits * x.numel() * 4, x.device)
+        check(L.slm_rms_norm_splitk(out.data_ptr(), ws.data_ptr(), partial_splits, weight.data_ptr(),
+                                    res_ptr, x.numel() // dim, dim, float(eps), _dtype_code(x),
+                                    _stream()), "slm_rms_norm_splitk")
+        return
+    check(L.slm_rms_norm(out.data_ptr(), x.data_ptr(), weight.data_ptr(), res_ptr,
                          x.numel() // dim, dim, float(eps), _dtype_code(x), _stream()),
           "slm_rms_norm")
 

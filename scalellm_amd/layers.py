@@ -180,13 +180,15 @@ class _QLinearBase:
         self._ckpt = {}
 
     def _gemm(self, x: torch.Tensor, bias: Optional[torch.Tensor],
-              out: Optional[torch.Tensor]) -> torch.Tensor:
+              out: Optional[torch.Tensor], defer_splitk: bool = False) -> torch.Tensor:
         if self._packed is None:
             self._repack()
         x2 = x.reshape(-1, x.size(-1))
         if out is None:
             out = torch.empty(x2.size(0), self._packed.N, dtype=x.dtype, device=x.device)
-        kernels.gptq_gemm(x2, self._packed, out, bias)
+        # > 0: `out` was NOT written, that many fp32 split-K slabs wait in the device workspace for
+        # kernels.rms_norm(..., partial_splits=n) (kernels.gptq_gemm, defer_reduce)
+        self.deferred_splits = kernels.gptq_gemm(x2, self._packed, out, bias, defer_reduce=defer_splitk)
         return out
 
 
@@ -218,9 +220,11 @@ class RowParallelQLinear(_QLinearBase):
         self.input_is_parallelized = input_is_parallelized
 
     def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None,
-                reduce: bool = True) -> torch.Tensor:
+                reduce: bool = True, defer_splitk: bool = False) -> torch.Tensor:
         """reduce=False returns this rank's PARTIAL sums (no all-reduce, no bias): the caller owns
-        the reduction (custom_allreduce.XgmiAllReduce fuses it with the residual add + RMSNorm)."""
+        the reduction (custom_allreduce.XgmiAllReduce fuses it with the residual add + RMSNorm).
+        defer_splitk (single rank, no bias): a split-K GEMM leaves its fp32 slabs for the RMSNorm
+        that follows (self.deferred_splits > 0 then, and the returned tensor is NOT written)."""
         if self._packed is None:
             self._repack()
         if not self.input_is_parallelized and self.parallel_args.world_size > 1:
@@ -236,4 +240,5 @@ class RowParallelQLinear(_QLinearBase):
             if self.has_bias:
                 y.add_(self.bias)
             return y
-        return self._gemm(x, self.bias if self.has_bias else None, out)
+        return self._gemm(x, self.bias if self.has_bias else None, out,
+                          defer_splitk=defer_splitk and not self.has_bias)

@@ -275,6 +275,44 @@ def test_repeated_launches_are_bit_identical(M, K, N, env, monkeypatch):
     assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("M,K,N", [(256, 4096, 4096), (256, 14336, 4096), (32, 4096, 4096),
+                                   (32, 14336, 4096), (7, 4096, 1024), (1, 4096, 4096)])
+def test_deferred_splitk_reduce_into_rms_norm(M, K, N, dtype):
+    """SLM_W4_DEFER_REDUCE: a split-K GEMM leaves its fp32 slabs in the workspace and
+    slm_rms_norm_splitk sums them itself -- same order and rounding as the reduce kernel, so
+    out / residual must equal "GEMM -> reduce -> slm_rms_norm(+residual)" bit for bit."""
+    from scalellm_amd import kernels
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    case = helpers.make_quant_case(M + K, K, N, 128, "awq", dtype)
+    packed = _pack(case, dtype)
+    g = torch.Generator(device=DEV).manual_seed(K + M)
+    a = torch.randn(M, K, device=DEV, dtype=tdt, generator=g)
+    w = (1 + 0.1 * torch.randn(N, device=DEV, generator=g)).to(tdt)
+    res0 = torch.randn(M, N, device=DEV, dtype=tdt, generator=g)
+    c = torch.empty(M, N, device=DEV, dtype=tdt)
+    assert kernels.gptq_gemm(a, packed, c) == 0
+    out_ref, res_ref = torch.empty_like(c), res0.clone()
+    kernels.rms_norm(out_ref, c, w, 1e-5, res_ref)
+    c2 = torch.full_like(c, float("nan"))  # must not be needed when the reduce is deferred
+    n = kernels.gptq_gemm(a, packed, c2, defer_reduce=True)
+    out, res = torch.empty_like(c), res0.clone()
+    kernels.rms_norm(out, c2, w, 1e-5, res, partial_splits=n)
+    torch.cuda.synchronize()
+    if (M, K, N) in ((256, 14336, 4096), (32, 14336, 4096)):
+        assert n >= 2, "the down-projection shapes are split over K"
+    if n == 0:
+        assert torch.equal(c2, c)
+    assert torch.equal(out, out_ref) and torch.equal(res, res_ref)
+    # without a residual too
+    out_b, out_b_ref = torch.empty_like(c), torch.empty_like(c)
+    kernels.rms_norm(out_b_ref, c, w, 1e-5)
+    n = kernels.gptq_gemm(a, packed, c2, defer_reduce=True)
+    kernels.rms_norm(out_b, c2, w, 1e-5, partial_splits=n)
+    torch.cuda.synchronize()
+    assert torch.equal(out_b, out_b_ref)
+
+
 def test_gemm_linearity_and_strided_rows():
     # size-independent property: GEMM is linear in A; also A / C row strides (lda, ldc > width)
     from scalellm_amd import kernels
