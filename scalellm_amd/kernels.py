@@ -49,6 +49,7 @@ def _stream() -> int:
 # outside graph capture (call reserve_workspace before capturing), never freed.
 # ---------------------------------------------------------------------------------------
 _workspaces = {}
+_deferred_partials = {}  # device -> (pointer, n_splits, elements per slab) of the last deferred GEMM
 
 
 def reserve_workspace(nbytes: int, device: Optional[torch.device] = None) -> torch.Tensor:
@@ -321,6 +322,10 @@ def gptq_gemm(a: torch.Tensor, packed: PackedW4, c: torch.Tensor,
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
     deferred = L.slm_w4a16_gemm_deferred_splits(C.byref(g)) if defer_reduce else 0
     check(L.slm_w4a16_gemm(C.byref(g), _stream()), "slm_w4a16_gemm")
+    if deferred:
+        # where the slabs are: the consumer must read THIS address even if the workspace is
+        # re-reserved (grown, hence moved) between the two calls
+        _deferred_partials[(a.device.type, a.device.index)] = (g.workspace, deferred, g.M * g.N)
     return deferred
 
 
@@ -353,8 +358,10 @@ def rms_norm(out: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, eps: floa
     dim = x.size(-1)
     res_ptr = residual.data_ptr() if residual is not None else None
     if partial_splits > 0:
-        ws = reserve_workspace(partial_splits * x.numel() * 4, x.device)
-        check(L.slm_rms_norm_splitk(out.data_ptr(), ws.data_ptr(), partial_splits, weight.data_ptr(),
+        rec = _deferred_partials.get((x.device.type, x.device.index))
+        if rec is None or rec[1] != partial_splits or rec[2] != x.numel():
+            raise SlmError("rms_norm(partial_splits=...) does not match the last deferred GEMM on this device")
+        check(L.slm_rms_norm_splitk(out.data_ptr(), rec[0], partial_splits, weight.data_ptr(),
                                     res_ptr, x.numel() // dim, dim, float(eps), _dtype_code(x),
                                     _stream()), "slm_rms_norm_splitk")
         return
