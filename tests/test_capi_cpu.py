@@ -168,3 +168,32 @@ def test_product_path_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and \
                     "libslm_oracle" not in txt, f"{f} references the oracle"
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """ABI drift guard: size and every field offset of the ctypes mirrors (_lib.py) equal what a C
+    compiler makes of include/slm_hip.h."""
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    from scalellm_amd._lib import ArArgs, W4GemmArgs
+    structs = {"slm_attn_args": AttnArgs, "slm_w4_gemm_args": W4GemmArgs, "slm_ar_args": ArArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "slm_hip.h"', 'int main(void) {']
+    for cname, ct in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-I", os.path.dirname(HEADER), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True)
+    seen = 0
+    for line in out.splitlines():
+        cname, field, val = line.split()
+        ct = structs[cname]
+        want = C.sizeof(ct) if field == "size" else getattr(ct, field).offset
+        assert int(val) == want, f"{cname}.{field}: C says {val}, ctypes says {want}"
+        seen += 1
+    assert seen == sum(len(ct._fields_) + 1 for ct in structs.values())
