@@ -143,6 +143,32 @@ def test_w4_host_side_planning_and_validation():
     assert L.slm_set_kv_cache(None, None, None, 0, 0, None, None, 3, 8, 128, 1, None) == -1
 
 
+def test_deferred_splitk_reduce_host_side():
+    """SLM_W4_DEFER_REDUCE: whether a call defers is a pure function of its argument block, and
+    slm_rms_norm_splitk validates before any launch."""
+    L = _lib.lib()
+    for k in [k for k in os.environ if k.startswith("SLM_W4_")]:
+        os.environ.pop(k)
+    g = W4GemmArgs()
+    g.M, g.K, g.N, g.lda, g.ldc, g.group_size, g.dtype = 256, 14336, 4096, 14336, 4096, 128, 1
+    assert L.slm_w4a16_gemm_deferred_splits(C.byref(g)) == 0          # flag not set
+    g.flags = _lib.SLM_W4_DEFER_REDUCE
+    n = L.slm_w4a16_gemm_deferred_splits(C.byref(g))
+    assert n >= 2                                                      # the down projection is split over K
+    assert L.slm_w4a16_gemm_workspace_bytes(C.byref(g)) == n * 256 * 4096 * 4
+    g.bias = 4096                                                      # bias: reduced as usual
+    assert L.slm_w4a16_gemm_deferred_splits(C.byref(g)) == 0
+    g.bias = None
+    g.N, g.ldc = 28672, 28672                                          # gate_up at M = 256: never split
+    g.K, g.lda = 4096, 4096
+    assert L.slm_w4a16_gemm_deferred_splits(C.byref(g)) == 0
+    assert L.slm_rms_norm_splitk(256, None, 4, 256, None, 8, 4096, 1e-5, 1, None) == -1   # no partials
+    assert L.slm_rms_norm_splitk(256, 256, 0, 256, None, 8, 4096, 1e-5, 1, None) == -1    # n_splits < 1
+    assert L.slm_rms_norm_splitk(256, 256, 4, 256, None, 8, 4100, 1e-5, 1, None) == -2    # dim % 8
+    assert L.slm_rms_norm_splitk(256, 264, 4, 256, None, 8, 4096, 1e-5, 1, None) == -5    # alignment
+    assert L.slm_rms_norm_splitk(256, 256, 4, 256, None, 0, 4096, 1e-5, 1, None) == 0     # empty batch
+
+
 def test_python_mirror_fails_loudly_on_cpu_tensors():
     """No CPU / PyTorch fallback anywhere in the product path."""
     from scalellm_amd import kernels
