@@ -53,6 +53,19 @@ SLM_API const char* slm_version(void);
 SLM_API const char* slm_last_hip_error(void);
 
 /* ========================================================================== */
+/* 0. Launch-shape overrides (sweeps, tests that force one kernel).           */
+/*    The library never reads the environment per call: the SLM_* variables   */
+/*    (SLM_ATTN_NW, SLM_ATTN_SPLITS, SLM_W4_MT, SLM_W4_SPLITK ... -- the full */
+/*    list is scalellm_amd/csrc/tuning.h) are parsed ONCE, at first use, and   */
+/*    only these calls change a knob afterwards.  Process-wide; not meant to  */
+/*    be flipped while other threads launch.  name = the variable's name.     */
+/*    slm_tuning_clear(NULL) clears every knob (environment values included). */
+/* ========================================================================== */
+SLM_API int slm_tuning_set(const char* name, int32_t value);
+SLM_API int slm_tuning_clear(const char* name);
+SLM_API int slm_tuning_get(const char* name, int32_t* value, int32_t* is_set);
+
+/* ========================================================================== */
 /* 1. Paged-KV varlen attention (prefill / chunked prefill / decode / verify) */
 /*    replaces  llm::paged_kv_varlen_mha                                      */
 /*              src/kernels/attention/attn_api.h:12-27 (impl attn_api.cpp:14) */
@@ -141,7 +154,8 @@ SLM_API int slm_set_kv_cache(const int32_t* slot_ids,  /* [n_tokens]           *
 /*      wq  [K/64][N/32][64 lanes][4] uint32  -- lane l, word j holds the 8   */
 /*           nibbles n = 32*nt + (l&31), k = 64*kt + 16*j + 8*(l>>5) + p'     */
 /*           in a pair-interleaved nibble order (MFMA 32x32x16 B-fragment);   */
-/*      sz  [G][N] {scale, -zero*scale} as 2 x T  (fused scale/zero table);   */
+/*      sz  [G][N] {scale, magic + zero} as 2 x T (magic = 128 for bf16,      */
+/*           1024 for fp16: the sum is exact in T; fused scale/zero table);   */
 /*      perm[K] int32 (act-order only): row k' of wq = checkpoint row perm[k']*/
 /* ========================================================================== */
 typedef enum slm_w4_format { SLM_W4_GPTQ = 0, SLM_W4_AWQ = 1 } slm_w4_format;

@@ -124,6 +124,9 @@ def lib() -> C.CDLL:
         ("slm_decode_advance", C.c_int,
          [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
           C.c_void_p, C.c_void_p]),
+        ("slm_tuning_set", C.c_int, [C.c_char_p, C.c_int32]),
+        ("slm_tuning_clear", C.c_int, [C.c_char_p]),
+        ("slm_tuning_get", C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
         ("slm_shm_alloc", C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.c_int32]),
         ("slm_shm_free", C.c_int, [C.c_void_p]),
         ("slm_shm_export", C.c_int, [C.c_void_p, C.c_char_p]),

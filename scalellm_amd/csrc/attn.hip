@@ -24,6 +24,7 @@
 //    exact conditional rescale (skipped when no running max moved in the wave).
 //  * split-KV partials (m, l, O) + combine kernel (math of attn_combine_kernel.cuh:14-21).
 #include "attn_common.h"
+#include "tuning.h"
 
 namespace slm {
 
@@ -390,6 +391,8 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const AttnKParams p, 
   const int64_t item = (int64_t)blockIdx.x * 4 + wv;
   if (item >= (int64_t)p.n_tokens * p.n_heads) return;
   const int tok = (int)(item / p.n_heads), head = (int)(item % p.n_heads);
+  // graph-padding rows past q_cu_lens[batch]: no kernel of the call wrote their partials
+  if (tok >= p.q_cu[p.batch]) return;
   if (p.rows_hi != 0x7fffffff || p.rows_lo != 0) {
     // mixed call: only the rows the token-major kernel produced are combined
     int lo_b = 0, hi_b = p.batch;
@@ -473,11 +476,6 @@ struct AttnPlan {
   size_t lds_bytes;
 };
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
-
 static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
   if (!a) return SLM_ERR_INVALID_ARG;
   if (a->n_heads <= 0 || a->n_kv_heads <= 0 || a->n_heads % a->n_kv_heads) return SLM_ERR_INVALID_ARG;
@@ -498,13 +496,13 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
   const int nhg = a->n_kv_heads / hpw;
   // Launch shape tuned on MI355X (tools/sweep_attn.py, profiles/attn_sweep_r1.md): 4 waves per
   // workgroup, ~256 workgroups per launch, >= 64 KV rows per split.
-  pl->nw = env_int("SLM_ATTN_NW", 4);
+  pl->nw = tune_get(TUNE_ATTN_NW, 4);
   if (pl->nw != 1 && pl->nw != 2 && pl->nw != 4 && pl->nw != 8) pl->nw = 4;
   const size_t state = (size_t)10 * pl->gc * 64 * sizeof(float);
   const int64_t target_wgs = 256;
   const int64_t max_by_len = (a->max_kv_len > 64 ? a->max_kv_len : 64) / 64;
-  int forced_splits = a->num_splits > 0 ? a->num_splits : env_int("SLM_ATTN_SPLITS", 0);
-  int hgw_cap = env_int("SLM_ATTN_HGW", pl->nw);
+  int forced_splits = a->num_splits > 0 ? a->num_splits : tune_get(TUNE_ATTN_SPLITS, 0);
+  int hgw_cap = tune_get(TUNE_ATTN_HGW, pl->nw);
   int hgw = 1, n_splits = 1;
   for (int pass = 0; pass < 2; ++pass) {
     // LDS: table + HGW x per-wave exchange state, kept under the 64 KiB default dynamic limit
@@ -520,7 +518,7 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
     n_splits = forced_splits > 0 ? forced_splits : (int)want;
     // tiny batches: if the grid is still short of one workgroup per CU, stop sharing a
     // workgroup between head groups (doubles / quadruples the workgroup count)
-    if (pass == 0 && base * n_splits < target_wgs && hgw > 1 && getenv("SLM_ATTN_HGW") == nullptr)
+    if (pass == 0 && base * n_splits < target_wgs && hgw > 1 && !tune_is_set(TUNE_ATTN_HGW))
       hgw_cap = 1;
     else
       break;
@@ -533,13 +531,13 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
   // HBM latency, so the KV range is split for it too (same partial format, same combine pass).
   // The count is shared by every kernel of the call.  Plain prefill (kv ~ q) is never split.
   if (a->max_q_len > 1 && forced_splits <= 0 && attn_tile_supported(D) &&
-      env_int("SLM_ATTN_TILE", 1) != 0 && a->max_kv_len >= 4 * (int64_t)a->max_q_len) {
+      tune_get(TUNE_ATTN_TILE, 1) != 0 && a->max_kv_len >= 4 * (int64_t)a->max_q_len) {
     const int64_t rows_max = (int64_t)a->max_q_len * G;
     const int64_t nw_t = rows_max <= 32 ? 1 : rows_max <= 64 ? 2 : 4;
     int64_t tiles = ((int64_t)a->n_tokens * G + 32 * nw_t - 1) / (32 * nw_t);
     if (tiles < a->batch_size) tiles = a->batch_size;
     const int64_t waves = tiles * a->n_kv_heads * nw_t;
-    int64_t want = env_int("SLM_ATTN_TILE_SPLITS", 0);
+    int64_t want = tune_get(TUNE_ATTN_TILE_SPLITS, 0);
     if (want <= 0) {
       // just enough to put a wave on every SIMD: measured (tools/bench_prefill.py), splitting
       // beyond that never pays -- with the chip full the kernel sits at its memory-system rate
@@ -553,9 +551,9 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
   }
   if (n_splits > COMBINE_MAX_SPLITS) n_splits = COMBINE_MAX_SPLITS;
   pl->n_splits = n_splits;
-  pl->u = env_int("SLM_ATTN_U", 4);
+  pl->u = tune_get(TUNE_ATTN_U, 4);
   if (pl->u != 2 && pl->u != 4) pl->u = 4;
-  pl->nt = env_int("SLM_ATTN_NT", a->max_q_len <= 1 ? 1 : 0) != 0;
+  pl->nt = tune_get(TUNE_ATTN_NT, a->max_q_len <= 1 ? 1 : 0) != 0;
   return SLM_OK;
 }
 
@@ -682,16 +680,19 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
   }
   bool tile_used = false;
   if (a->max_q_len > 1 && a->num_splits <= 0 && attn_tile_supported(kp.head_dim) &&
-      env_int("SLM_ATTN_TILE", 1) != 0) {
+      tune_get(TUNE_ATTN_TILE, 1) != 0) {
     hip_clear_error();
     const int64_t max_rows = (int64_t)a->max_q_len * kp.group;
     AttnKParams tk = kp;
-    tk.rows_lo = kp.group + 1;
-    tk.rows_hi = 33;
-    rc = launch_attn_tile(tk, a->dtype, max_rows < 32 ? max_rows : 32, st);
-    if (rc != SLM_OK) return rc;
+    if (kp.group + 1 < 33) {  // (group >= 32: every multi-row sequence already has > 32 rows)
+      tk.rows_lo = kp.group + 1;
+      tk.rows_hi = 33;
+      rc = launch_attn_tile(tk, a->dtype, max_rows < 32 ? max_rows : 32, st);
+      if (rc != SLM_OK) return rc;
+    }
     if (max_rows > 32) {
-      tk.rows_lo = 33;
+      // rows <= group (q_len = 1) stay with the token-major kernel also when group > 32 (MQA)
+      tk.rows_lo = kp.group + 1 > 33 ? kp.group + 1 : 33;
       tk.rows_hi = 0x7fffffff;
       rc = launch_attn_tile(tk, a->dtype, max_rows, st);
       if (rc != SLM_OK) return rc;

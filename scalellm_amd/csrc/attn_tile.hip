@@ -25,6 +25,7 @@
 // K/V rows are gathered through the block table (slot = table[i >> log2 bs] + (i & (bs-1)),
 // bit-exact with sm80_kernel_mha.cuh:146-152) by all waves of the workgroup, 16 B per lane.
 #include "attn_common.h"
+#include "tuning.h"
 
 namespace slm {
 
@@ -355,8 +356,7 @@ int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t rows, hipStream_t
   const int64_t grid = tiles_per_seq * kp.n_kv_heads * kp.batch * kp.n_splits;
   if (grid <= 0 || grid > 0x7fffffffLL) return SLM_ERR_UNSUPPORTED;
   const dim3 g((unsigned)grid), blk(64 * nw);
-  const char* pfe = getenv("SLM_ATTN_TILE_PF");
-  const bool pf = !(pfe && pfe[0] == '0');
+  const bool pf = tune_get(TUNE_ATTN_TILE_PF, 1) != 0;
   const bool plain = kp.softcap <= 0.f && kp.alibi == nullptr && kp.window < 0;
 #define SLM_TILE(TT, HDD, NWW)                                                                    \
   do {                                                                                            \

@@ -7,6 +7,7 @@
 // and at::cuda::getCurrentCUDAStream() resolve to in a hipified torch build.
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/hip/HIPGraphsC10Utils.h>
 #include <rccl/rccl.h>
 
 #include <mutex>
@@ -35,19 +36,37 @@ void check(int rc, const char* what) {
 }
 
 // one growable scratch buffer per device (split-KV / split-K partials); grown outside capture
+//
+// Lifetime rule: a buffer that was ever handed to a kernel is NEVER released.  The reference
+// captures its graphs in ascending batch size, each after a warm-up (llm_engine.cpp:79,223;
+// model_runner.cpp:162-175), and eager prefills may grow the scratch again later; a graph
+// captured earlier keeps replaying against the raw address it recorded.  Growth therefore RETIRES
+// the old buffer (kept alive in g_retired) and at least doubles, so the retired total stays below
+// the final size.  Sizing it once up front (paged_kv_varlen_mha_set_workspace, one tensor per
+// device) avoids retirements altogether.  Growth during stream capture is refused.
 std::mutex g_ws_mu;
-std::unordered_map<int, torch::Tensor> g_ws;
-torch::Tensor g_user_ws;
+std::unordered_map<int, torch::Tensor> g_ws;       // device index -> current scratch
+std::unordered_map<int, torch::Tensor> g_user_ws;  // device index -> caller-supplied scratch
+std::vector<torch::Tensor> g_retired;              // replaced buffers (earlier captures point here)
 
 torch::Tensor workspace_for(const torch::Tensor& like, size_t bytes) {
   std::lock_guard<std::mutex> lk(g_ws_mu);
-  if (g_user_ws.defined() && g_user_ws.device() == like.device() &&
-      static_cast<size_t>(g_user_ws.nbytes()) >= bytes)
-    return g_user_ws;
-  auto& ws = g_ws[like.device().index()];
+  const int dev = like.device().index();
+  auto user = g_user_ws.find(dev);
+  if (user != g_user_ws.end() && static_cast<size_t>(user->second.nbytes()) >= bytes)
+    return user->second;
+  auto& ws = g_ws[dev];
   if (!ws.defined() || static_cast<size_t>(ws.nbytes()) < bytes) {
-    ws = torch::empty({static_cast<int64_t>(std::max<size_t>(bytes, 1 << 20))},
-                      torch::dtype(torch::kUInt8).device(like.device()));
+    const auto capturing = c10::hip::currentStreamCaptureStatusMayInitCtx();
+    TORCH_CHECK(capturing == c10::hip::CaptureStatus::None,
+                "slm: the kernel workspace must be sized before graph capture (need ", bytes,
+                " bytes): warm the step up first or call paged_kv_varlen_mha_set_workspace()");
+    size_t size = std::max<size_t>(bytes, 1 << 20);
+    if (ws.defined()) {
+      size = std::max<size_t>(size, 2 * static_cast<size_t>(ws.nbytes()));
+      g_retired.push_back(ws);
+    }
+    ws = torch::empty({static_cast<int64_t>(size)}, torch::dtype(torch::kUInt8).device(like.device()));
   }
   return ws;
 }
@@ -108,8 +127,14 @@ int64_t paged_kv_varlen_mha_workspace_size(int64_t n_tokens, int64_t n_heads, in
 }
 
 void paged_kv_varlen_mha_set_workspace(const torch::Tensor& workspace) {
+  TORCH_CHECK(workspace.defined() && workspace.is_cuda() && workspace.is_contiguous(),
+              "set_workspace: a contiguous device tensor");
   std::lock_guard<std::mutex> lk(g_ws_mu);
-  g_user_ws = workspace;
+  // one per device (thread-per-GPU engines call this once per worker); a replaced tensor stays
+  // alive: graphs captured against it may still replay
+  auto& slot = g_user_ws[workspace.device().index()];
+  if (slot.defined()) g_retired.push_back(slot);
+  slot = workspace;
 }
 
 namespace kernel {

@@ -1,0 +1,43 @@
+// tuning.h -- launch-shape overrides of libslm_hip, in ONE table.
+//
+// The kernels' launch heuristics (plan_attn, plan_gemm, ...) have override knobs for sweeps and
+// for tests that force a particular kernel.  They are NOT read from the environment per call: the
+// SLM_* environment variables are parsed exactly once, when the library is first used, into this
+// table; afterwards only the explicit C-ABI setter (slm_tuning_set / slm_tuning_clear,
+// include/slm_hip.h section 0) changes it.  A lookup is one relaxed atomic load.
+#pragma once
+#include <stdint.h>
+
+namespace slm {
+
+enum TuneKey : int {
+  TUNE_ATTN_NW = 0,       // SLM_ATTN_NW           waves per token-kernel workgroup (1/2/4/8)
+  TUNE_ATTN_SPLITS,       // SLM_ATTN_SPLITS       forced split-KV count
+  TUNE_ATTN_HGW,          // SLM_ATTN_HGW          head groups per workgroup cap
+  TUNE_ATTN_TILE,         // SLM_ATTN_TILE         0 = never use the MFMA tile kernel
+  TUNE_ATTN_TILE_SPLITS,  // SLM_ATTN_TILE_SPLITS  forced split count of the tile kernel
+  TUNE_ATTN_TILE_PF,      // SLM_ATTN_TILE_PF      tile kernel prefetch variant
+  TUNE_ATTN_U,            // SLM_ATTN_U            K/V register ring depth (2/4)
+  TUNE_ATTN_NT,           // SLM_ATTN_NT           non-temporal KV loads on/off
+  TUNE_ATTN_FUSED_COMBINE,  // SLM_ATTN_FUSED_COMBINE  0 = separate combine launch
+  TUNE_W4_GEMV,           // SLM_W4_GEMV           0 off, 1 = M == 1 only, 2 = M <= 4
+  TUNE_W4_GEMV_REFILL,    // SLM_W4_GEMV_REFILL
+  TUNE_W4_SMALL,          // SLM_W4_SMALL          0 = never use the small-M kernel
+  TUNE_W4_MT,             // SLM_W4_MT             forced M tile (1/2/4/8/16)
+  TUNE_W4_NTW,            // SLM_W4_NTW
+  TUNE_W4_PC,             // SLM_W4_PC
+  TUNE_W4_SPLITK,         // SLM_W4_SPLITK         forced split-K
+  TUNE_W4_POST,           // SLM_W4_POST
+  TUNE_W4_FUSED_REDUCE,   // SLM_W4_FUSED_REDUCE   0 = separate split-K reduce launch
+  TUNE_W4_STREAM,         // SLM_W4_STREAM         0 = never use the barrier-free small-M stream kernel
+  TUNE_W4_STREAM_KW,      // SLM_W4_STREAM_KW      forced in-workgroup K split of the stream kernel
+  TUNE_COUNT
+};
+
+constexpr int32_t TUNE_UNSET = INT32_MIN;
+
+// value of the knob, or `dflt` when it was never set
+int tune_get(TuneKey k, int dflt);
+bool tune_is_set(TuneKey k);
+
+}  // namespace slm

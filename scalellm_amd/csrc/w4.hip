@@ -35,6 +35,7 @@
 //    prefill-sized M x N             w4_xl.hip     symmetric 256 x 256 tiles
 // (DESIGN.md 3.3 has the measurements behind each boundary.)
 #include "w4_common.h"
+#include "tuning.h"
 
 namespace slm {
 
@@ -428,11 +429,6 @@ struct GemmPlan {
   size_t lds_bytes, part_bytes, aperm_bytes;
 };
 
-static int w4_env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
-
 static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   if (!a) return SLM_ERR_INVALID_ARG;
   if (a->M < 0 || a->K <= 0 || a->N <= 0) return SLM_ERR_INVALID_ARG;
@@ -472,18 +468,18 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   // M <= 4: dot2 GEMV (w4_gemv.hip); M <= 32: the lean weight-streaming kernel (w4_small.hip)
   // (measured: the GEMV wins on every layer shape at M = 1 and loses on some at M = 2..4, so the
   // default is M = 1 only; SLM_W4_GEMV=2 forces it for M <= 4; its 32-bit offsets need < 4 GiB tables)
-  const int gemv_mode = w4_env_int("SLM_W4_GEMV", 1);
+  const int gemv_mode = tune_get(TUNE_W4_GEMV, 1);
   pl->gemv = (gemv_mode != 0 && (a->M == 1 || gemv_mode == 2) && gemv_supported(a->M, a->K, gs) &&
               a->K * a->N / 2 < ((int64_t)1 << 32) && (a->K / gs) * a->N * 4 < ((int64_t)1 << 32)) ? 1 : 0;
-  pl->small = (a->M <= 32 && w4_env_int("SLM_W4_SMALL", 1) != 0 &&
+  pl->small = (a->M <= 32 && tune_get(TUNE_W4_SMALL, 1) != 0 &&
                a->K * a->N / 2 < ((int64_t)1 << 32) && (a->K / gs) * a->N * 4 < ((int64_t)1 << 32) &&
                ((a->M - 1) * a->lda + a->K) * 2 < ((int64_t)1 << 31)) ? 1 : 0;
-  mt = w4_env_int("SLM_W4_MT", mt);
+  mt = tune_get(TUNE_W4_MT, mt);
   if (pl->small) mt = 1;
   // 8 = wave-specialised 256 x 128 kernel (w4_ws.hip), 16 = symmetric 256 x 256 kernel (w4_xl.hip)
   if (mt != 1 && mt != 2 && mt != 4 && mt != 8 && mt != 16) mt = 4;
   if (mt >= 8 && ((a->M - 1) * a->lda + a->K) * 2 >= ((int64_t)1 << 31)) mt = 4;
-  int ntw = w4_env_int("SLM_W4_NTW", 1);
+  int ntw = tune_get(TUNE_W4_NTW, 1);
   if (ntw != 1 && ntw != 2) ntw = 1;
   if (mt >= 4) ntw = 1;
   pl->mt = mt;
@@ -493,12 +489,12 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   pl->n_nblocks = (int)((a->N + bn - 1) / bn);
   const int64_t tiles = (int64_t)pl->n_mblocks * pl->n_nblocks;
   // pass = PC chunks per LDS buffer (PC*MT <= 4); one chunk per pass measured best or equal
-  int pc = w4_env_int("SLM_W4_PC", 1);
+  int pc = tune_get(TUNE_W4_PC, 1);
   if (pc != 1 && pc != 2 && pc != 4) pc = 1;
   if (pc * mt > 4) pc = mt >= 4 ? 1 : 4 / mt;
   while (pc > 1 && n_chunks % pc) pc >>= 1;
   const int n_units = n_chunks / pc;  // split-K granularity = whole passes
-  int split_k = w4_env_int("SLM_W4_SPLITK", 0);
+  int split_k = tune_get(TUNE_W4_SPLITK, 0);
   if (split_k <= 0) {
     const int64_t target = (a->M <= 64 || mt >= 8) ? 256 : 512;
     int64_t want = (target + tiles / 2) / (tiles > 0 ? tiles : 1);
@@ -517,7 +513,7 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   pl->chunks_per_split = units_per_split * pc;
   pl->split_k = (n_units + units_per_split - 1) / units_per_split;
   // small-M tiles use the post-scaled form (7 VALU per 8 weights instead of ~27)
-  pl->post = w4_env_int("SLM_W4_POST", a->M <= 64 ? 1 : 0) != 0 && mt <= 2;
+  pl->post = tune_get(TUNE_W4_POST, a->M <= 64 ? 1 : 0) != 0 && mt <= 2;
   pl->lds_bytes = (size_t)2 * pc * bm * 256 + (pl->post ? (size_t)2 * pc * pl->ng * bm * sizeof(float) : 0);
   if (pl->gemv) {  // K is split inside the workgroup: no partials, no reduce launch
     pl->split_k = 1;

@@ -20,6 +20,7 @@
 // the other small-M kernels): within the reference tests' GEMM tolerance, not bit-identical to
 // "dequantise to T, then multiply".
 #include "w4_common.h"
+#include "tuning.h"
 
 namespace slm {
 
@@ -226,8 +227,7 @@ static void launch_gemv_m(const GemvParams& gp, int n_wgs, size_t lds, hipStream
   // measured: keeping the (clamped, L2-hit) refills even when the slice fits the ring is FASTER on
   // the wide layers (gate_up M=1 17.5-19 us vs 23.4 us without them) -- the extra loads keep the
   // issue pattern the compiler's counted waits were built for; SLM_W4_GEMV_REFILL=0 disables them
-  const char* ev = getenv("SLM_W4_GEMV_REFILL");
-  const bool refill = (gp.n64 + gp.ks - 1) / gp.ks > GV_RING || !(ev && ev[0] == '0');
+  const bool refill = (gp.n64 + gp.ks - 1) / gp.ks > GV_RING || tune_get(TUNE_W4_GEMV_REFILL, 1) != 0;
 #define SLM_GEMV(MTT)                                                                          \
   do {                                                                                         \
     auto kfn = refill ? w4a16_gemv_kernel<T, NGC, MTT, true> : w4a16_gemv_kernel<T, NGC, MTT, false>; \

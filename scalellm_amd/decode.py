@@ -223,7 +223,7 @@ class LlamaDecodeStep:
             resid.copy_(x)
             o_buf, down_buf = b["o"][:T], b["down"][:T]
 
-        def reduce_add_norm(i: int, partial: torch.Tensor, weight: torch.Tensor, splits: int = 0) -> None:
+        def reduce_add_norm(i: int, partial: torch.Tensor, weight: torch.Tensor, deferred=None) -> None:
             """normed = RMSNorm(all-reduce(partial) + resid) * weight, resid updated in place
             (reduce_from_model_parallel_region + rms_norm_residual, or the fused launch)."""
             if ar is not None:
@@ -232,7 +232,7 @@ class LlamaDecodeStep:
                 if pa.world_size > 1:
                     pa.process_group.allreduce(partial)
                 kernels.rms_norm(normed, partial, weight, s.rms_eps, residual=resid,
-                                 partial_splits=splits)
+                                 partials=deferred)
 
         kernels.rms_norm(normed, resid, self.layers[0]["in_norm"], s.rms_eps)
         for li, L in enumerate(self.layers):
@@ -244,13 +244,13 @@ class LlamaDecodeStep:
             # and one activation round trip less per row-parallel linear)
             defer = pa.world_size == 1 and os.environ.get("SLM_DEFER_SPLITK", "1") != "0"
             delta = L["o"].forward(attn, out=o_buf, reduce=False, defer_splitk=defer)
-            reduce_add_norm(0, delta, L["post_norm"], L["o"].deferred_splits if defer else 0)
+            reduce_add_norm(0, delta, L["post_norm"], L["o"].deferred if defer else None)
             gu = L["gate_up"].forward(normed, out=b["gate_up"][:T])
             kernels.silu_and_mul(b["act"][:T], gu)
             delta = L["down"].forward(b["act"][:T], out=down_buf, reduce=False, defer_splitk=defer)
             # the NEXT block's input norm (or the final norm) consumes this reduction
             nxt = self.layers[li + 1]["in_norm"] if li + 1 < len(self.layers) else self.final_norm
-            reduce_add_norm(1, delta, nxt, L["down"].deferred_splits if defer else 0)
+            reduce_add_norm(1, delta, nxt, L["down"].deferred if defer else None)
         last = (params.q_cu_seq_lens[1:] - 1).long()
         logits = normed[last] @ self.lm_head  # plain library GEMM (hipBLASLt): not on the graded path
         if ar is not None and not return_logits and last.numel() <= ar.max_tokens \

@@ -16,6 +16,7 @@ There is NO fallback: a missing library or a non-GPU tensor raises.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Optional
 
@@ -45,24 +46,100 @@ def _stream() -> int:
 
 
 # ---------------------------------------------------------------------------------------
-# workspace (split-KV partials, split-K partials): one growable buffer per device.  Grown
-# outside graph capture (call reserve_workspace before capturing), never freed.
+# launch-shape overrides (sweeps / tests that force one kernel): the library reads the SLM_*
+# environment once, at first use; afterwards only this explicit setter changes a knob
+# (include/slm_hip.h section 0, csrc/tuning.h)
+# ---------------------------------------------------------------------------------------
+@contextlib.contextmanager
+def tuning(**knobs: int):
+    """with kernels.tuning(SLM_W4_MT=8, SLM_W4_SPLITK=2): ...   (restores the previous values)"""
+    L = _lib.lib()
+    saved = {}
+    for name, val in knobs.items():
+        v, s = C.c_int32(0), C.c_int32(0)
+        check(L.slm_tuning_get(name.encode(), C.byref(v), C.byref(s)), f"slm_tuning_get({name})")
+        saved[name] = (v.value, s.value)
+        if val is None:
+            check(L.slm_tuning_clear(name.encode()), f"slm_tuning_clear({name})")
+        else:
+            check(L.slm_tuning_set(name.encode(), int(val)), f"slm_tuning_set({name})")
+    try:
+        yield
+    finally:
+        for name, (v, s) in saved.items():
+            if s:
+                L.slm_tuning_set(name.encode(), v)
+            else:
+                L.slm_tuning_clear(name.encode())
+
+
+def clear_tuning() -> None:
+    """Drop every override, including the ones the environment supplied at load time."""
+    check(_lib.lib().slm_tuning_clear(None), "slm_tuning_clear")
+
+
+# ---------------------------------------------------------------------------------------
+# workspaces.  One growable scratch buffer per device (split-KV partials, split-K partials,
+# act-order activation copy) and a SEPARATE one for deferred split-K partials (a producer ->
+# consumer hand-off that no other kernel's scratch may clobber).  Lifetime rule: a buffer that
+# was ever handed to a kernel is never released -- hipGraphs captured earlier keep replaying
+# against its raw address (the reference captures graphs in ascending batch size, each after
+# a warm-up: llm_engine.cpp:79,223, model_runner.cpp:162-175).  Growth retires the old buffer
+# (kept alive in _retired) and doubles at least, so the retired total is bounded by the
+# final size.  Size it once up front with reserve_workspace() to avoid retirements.
 # ---------------------------------------------------------------------------------------
 _workspaces = {}
-_deferred_partials = {}  # device -> (pointer, n_splits, elements per slab) of the last deferred GEMM
+_deferred_ws = {}
+_retired = []  # buffers replaced by bigger ones: still referenced by graphs captured before
+_deferred_gen = {}  # device -> generation counter of the deferred-partials buffer
 
 
-def reserve_workspace(nbytes: int, device: Optional[torch.device] = None) -> torch.Tensor:
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
-    ws = _workspaces.get(key)
+def _dev_key(dev: torch.device):
+    return (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+def _grow(table, nbytes: int, dev: torch.device, what: str) -> torch.Tensor:
+    key = _dev_key(dev)
+    ws = table.get(key)
     if ws is None or ws.numel() < nbytes:
         if torch.cuda.is_current_stream_capturing():
-            raise SlmError("workspace must be reserved before graph capture "
+            raise SlmError(f"{what} must be reserved before graph capture "
                            f"(need {nbytes} bytes): call reserve_workspace() first")
-        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
-        _workspaces[key] = ws
+        size = max(int(nbytes), 1 << 20, 2 * ws.numel() if ws is not None else 0)
+        if ws is not None:
+            _retired.append(ws)  # never freed: earlier captures still point into it
+        ws = torch.empty(size, dtype=torch.uint8, device=dev)
+        table[key] = ws
     return ws
+
+
+def reserve_workspace(nbytes: int, device: Optional[torch.device] = None,
+                      deferred_nbytes: int = 0) -> torch.Tensor:
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    if deferred_nbytes:
+        _grow(_deferred_ws, deferred_nbytes, dev, "deferred split-K buffer")
+    return _grow(_workspaces, nbytes, dev, "workspace")
+
+
+def retired_workspace_bytes() -> int:
+    return sum(t.numel() for t in _retired)
+
+
+class DeferredPartials:
+    """Handle to the fp32 split-K slabs a gptq_gemm(..., defer_reduce=True) left behind, consumed
+    by rms_norm(..., partials=handle).  Falsy when the GEMM wrote `c` as usual."""
+
+    __slots__ = ("ptr", "splits", "numel", "key", "generation", "_keep")
+
+    def __init__(self, ptr=0, splits=0, numel=0, key=None, generation=0, keep=None):
+        self.ptr, self.splits, self.numel = ptr, splits, numel
+        self.key, self.generation, self._keep = key, generation, keep
+
+    def __bool__(self):
+        return self.splits > 0
+
+    def __int__(self):
+        return self.splits
 
 
 # ---------------------------------------------------------------------------------------
@@ -302,31 +379,40 @@ def _gemm_args(a, packed: PackedW4, c, bias) -> W4GemmArgs:
 
 
 def gptq_gemm(a: torch.Tensor, packed: PackedW4, c: torch.Tensor,
-              bias: Optional[torch.Tensor] = None, defer_reduce: bool = False) -> int:
+              bias: Optional[torch.Tensor] = None, defer_reduce: bool = False) -> DeferredPartials:
     """Mirror of marlin::gptq_gemm (marlin.h:17-25): C[M,N] = A[M,K] . dequant(W) (+ bias),
     fp32 accumulate, written into the pre-allocated `c`.  AWQ and GPTQ share it, as in the
     reference (has_zp true/false): zero points live in the prepacked scale/zero table.
 
-    defer_reduce: when the call is split over K, leave the fp32 partial sums in the device
-    workspace for the consumer (rms_norm(..., partial_splits=n)) instead of reducing them into
-    `c`.  Returns the number of partial slabs left behind (>= 2), or 0 when `c` was written."""
+    defer_reduce: when the call is split over K, leave the fp32 partial sums in a dedicated
+    device buffer for the consumer (rms_norm(..., partials=handle)) instead of reducing them into
+    `c`.  Returns a DeferredPartials handle: truthy (int(handle) = slab count >= 2) when slabs
+    were left behind and `c` was NOT written, falsy when `c` was written as usual."""
     L = _lib.lib()
     g = _gemm_args(a, packed, c, bias)
     if g.M == 0:
-        return 0
+        return DeferredPartials()
+    deferred = 0
     if defer_reduce:
         g.flags = _lib.SLM_W4_DEFER_REDUCE
+        deferred = L.slm_w4a16_gemm_deferred_splits(C.byref(g))
+        if not deferred:
+            g.flags = 0
     need = L.slm_w4a16_gemm_workspace_bytes(C.byref(g))
+    ws = None
     if need:
-        ws = reserve_workspace(need, a.device)
+        # deferred slabs live in their own buffer: attention split-KV scratch, other split-K GEMMs
+        # and act-order copies (which all use the shared workspace) can never overwrite them
+        ws = _grow(_deferred_ws, need, a.device, "deferred split-K buffer") if deferred else \
+            reserve_workspace(need, a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
-    deferred = L.slm_w4a16_gemm_deferred_splits(C.byref(g)) if defer_reduce else 0
     check(L.slm_w4a16_gemm(C.byref(g), _stream()), "slm_w4a16_gemm")
     if deferred:
-        # where the slabs are: the consumer must read THIS address even if the workspace is
-        # re-reserved (grown, hence moved) between the two calls
-        _deferred_partials[(a.device.type, a.device.index)] = (g.workspace, deferred, g.M * g.N)
-    return deferred
+        key = _dev_key(a.device)
+        gen = _deferred_gen.get(key, 0) + 1
+        _deferred_gen[key] = gen  # any older handle on this device is now stale
+        return DeferredPartials(g.workspace, deferred, g.M * g.N, key, gen, ws)
+    return DeferredPartials()
 
 
 def w4_dequant(packed: PackedW4) -> torch.Tensor:
@@ -343,12 +429,14 @@ def w4_dequant(packed: PackedW4) -> torch.Tensor:
 # glue ops (next rows f1/f2)
 # ---------------------------------------------------------------------------------------
 def rms_norm(out: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, eps: float,
-             residual: Optional[torch.Tensor] = None, partial_splits: int = 0) -> None:
+             residual: Optional[torch.Tensor] = None,
+             partials: Optional[DeferredPartials] = None) -> None:
     """kernel::rms_norm / rms_norm_residual (layernorm_kernels.cu:15,125).
 
-    partial_splits > 0: `x` was NOT written -- a gptq_gemm(..., defer_reduce=True) left that many
-    fp32 split-K slabs [splits, tokens, dim] at the start of the device workspace; the norm sums them
-    itself (same order and rounding as the reduce kernel: identical bits, one launch less)."""
+    partials (truthy): `x` was NOT written -- the gptq_gemm(..., defer_reduce=True) that returned
+    this handle left fp32 split-K slabs [splits, tokens, dim] in the deferred buffer; the norm sums
+    them itself (same order and rounding as the reduce kernel: identical bits, one launch less).
+    A handle is valid until the next deferred GEMM on the same device (checked)."""
     L = _lib.lib()
     _require_gpu(out, x, weight, residual)
     if not (x.is_contiguous() and out.is_contiguous() and weight.is_contiguous()):
@@ -357,11 +445,15 @@ def rms_norm(out: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, eps: floa
         raise SlmError("rms_norm needs a contiguous residual")
     dim = x.size(-1)
     res_ptr = residual.data_ptr() if residual is not None else None
-    if partial_splits > 0:
-        rec = _deferred_partials.get((x.device.type, x.device.index))
-        if rec is None or rec[1] != partial_splits or rec[2] != x.numel():
-            raise SlmError("rms_norm(partial_splits=...) does not match the last deferred GEMM on this device")
-        check(L.slm_rms_norm_splitk(out.data_ptr(), rec[0], partial_splits, weight.data_ptr(),
+    if partials:
+        if not isinstance(partials, DeferredPartials):
+            raise SlmError("rms_norm(partials=...) takes the handle gptq_gemm(defer_reduce=True) returned")
+        if partials.key != _dev_key(x.device) or partials.numel != x.numel():
+            raise SlmError("rms_norm(partials=...): the handle belongs to another device or shape")
+        if _deferred_gen.get(partials.key) != partials.generation:
+            raise SlmError("rms_norm(partials=...): stale handle -- a later deferred GEMM on this "
+                           "device has overwritten the slabs")
+        check(L.slm_rms_norm_splitk(out.data_ptr(), partials.ptr, partials.splits, weight.data_ptr(),
                                     res_ptr, x.numel() // dim, dim, float(eps), _dtype_code(x),
                                     _stream()), "slm_rms_norm_splitk")
         return
@@ -389,9 +481,28 @@ def apply_rotary_pos_emb(query: torch.Tensor, key: torch.Tensor, positions: torc
     is_f32 = 1 if cos_sin.dtype == torch.float32 else 0
     if not is_f32 and cos_sin.dtype != query.dtype:
         raise SlmError("cos_sin must be fp32 or the activation dtype")
+    if not positions.is_contiguous() or positions.numel() != query.size(0):
+        raise SlmError("positions must be contiguous int32 [n_tokens]")
+    if key.size(0) != query.size(0) or key.size(2) != query.size(2) or key.dtype != query.dtype:
+        raise SlmError("query / key token counts, head_dim and dtype must match")
     append = slot_ids is not None
-    if append and (value is None or key_cache is None or value_cache is None):
-        raise SlmError("append needs value, key_cache and value_cache")
+    if append:
+        # same contract as set_kv_cache: the kernel scatters dense [n_kv_heads, head_dim] rows
+        # through int32 slot ids
+        if value is None or key_cache is None or value_cache is None:
+            raise SlmError("append needs value, key_cache and value_cache")
+        if slot_ids.dtype != torch.int32 or not slot_ids.is_contiguous() or \
+                slot_ids.numel() != query.size(0):
+            raise SlmError("slot_ids must be contiguous int32 [n_tokens]")
+        if value.dim() != 3 or value.shape != key.shape or value.dtype != key.dtype or \
+                value.stride(-1) != 1 or value.stride(-2) != value.size(-1):
+            raise SlmError("value must be [n_tokens, n_kv_heads, head_dim], contiguous in its last "
+                           "two dims, same dtype as key")
+        for t in (key_cache, value_cache):
+            if not t.is_contiguous() or t.dtype != key.dtype or t.dim() != 3 or \
+                    tuple(t.shape[1:]) != tuple(key.shape[1:]):
+                raise SlmError("caches must be contiguous [n_slots, n_kv_heads, head_dim] of the "
+                               "activation dtype")
     check(L.slm_rope_kv_append(
         query.data_ptr(), query.stride(0), key.data_ptr(), key.stride(0),
         value.data_ptr() if append else None, value.stride(0) if append else 0,

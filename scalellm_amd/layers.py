@@ -186,9 +186,10 @@ class _QLinearBase:
         x2 = x.reshape(-1, x.size(-1))
         if out is None:
             out = torch.empty(x2.size(0), self._packed.N, dtype=x.dtype, device=x.device)
-        # > 0: `out` was NOT written, that many fp32 split-K slabs wait in the device workspace for
-        # kernels.rms_norm(..., partial_splits=n) (kernels.gptq_gemm, defer_reduce)
-        self.deferred_splits = kernels.gptq_gemm(x2, self._packed, out, bias, defer_reduce=defer_splitk)
+        # truthy: `out` was NOT written, fp32 split-K slabs wait in the deferred buffer for
+        # kernels.rms_norm(..., partials=handle) (kernels.gptq_gemm, defer_reduce)
+        self.deferred = kernels.gptq_gemm(x2, self._packed, out, bias, defer_reduce=defer_splitk)
+        self.deferred_splits = int(self.deferred)
         return out
 
 
@@ -224,7 +225,7 @@ class RowParallelQLinear(_QLinearBase):
         """reduce=False returns this rank's PARTIAL sums (no all-reduce, no bias): the caller owns
         the reduction (custom_allreduce.XgmiAllReduce fuses it with the residual add + RMSNorm).
         defer_splitk (single rank, no bias): a split-K GEMM leaves its fp32 slabs for the RMSNorm
-        that follows (self.deferred_splits > 0 then, and the returned tensor is NOT written)."""
+        that follows (self.deferred is truthy then, and the returned tensor is NOT written)."""
         if self._packed is None:
             self._repack()
         if not self.input_is_parallelized and self.parallel_args.world_size > 1:

@@ -1,3 +1,4 @@
+import contextlib
 import os
 import sys
 
@@ -25,3 +26,26 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def tune():
+    """tune(SLM_W4_MT=8, ...): force launch-shape knobs through the library's explicit setter
+    (slm_tuning_set) for the duration of one test; the previous values come back afterwards."""
+    from scalellm_amd import kernels
+    with contextlib.ExitStack() as stack:
+        def _set(**knobs):
+            stack.enter_context(kernels.tuning(**knobs))
+        yield _set
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _no_ambient_tuning():
+    """Tests must not depend on SLM_* variables that happen to be exported: drop whatever the
+    library picked up from the environment at load time."""
+    try:
+        from scalellm_amd import kernels
+        kernels.clear_tuning()
+    except Exception:  # library not built: the tests that need it fail on their own
+        pass
+    yield

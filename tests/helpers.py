@@ -169,3 +169,17 @@ def make_quant_case(seed, K, N, group_size, fmt, dtype_bits="bf16", act_order=Fa
         d = dict(qweight=pack_rows(q), qzeros=pack_cols(z_stored), z_eff=z_stored + 1)
     d.update(q=q, scales=s, scales_bits=s_bits, g_idx=g_idx, K=K, N=N, group_size=gs, fmt=fmt)
     return d
+
+
+def pack_case(case, bits="bf16", device="cuda"):
+    """make_quant_case() output -> scalellm_amd.kernels.PackedW4 on `device` (GPU tests only)."""
+    import torch
+    from scalellm_amd import kernels
+    dt = torch.bfloat16 if bits == "bf16" else torch.float16
+    qweight = torch.from_numpy(case["qweight"]).to(device)
+    qzeros = torch.from_numpy(case["qzeros"]).to(device)
+    scales = torch.from_numpy(case["scales_bits"].view(np.int16)).to(device).view(dt)
+    if case["fmt"] == "awq":
+        return kernels.awq_repack(qweight, qzeros, scales, case["group_size"])
+    g_idx = torch.from_numpy(case["g_idx"]).to(device) if case["g_idx"] is not None else None
+    return kernels.gptq_repack(qweight, qzeros, scales, case["group_size"], g_idx)

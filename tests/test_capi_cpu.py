@@ -48,6 +48,61 @@ def test_library_loads_without_gpu_and_reports_version():
     assert L.slm_status_string(-3) == b"workspace missing or too small"
 
 
+def test_tuning_table_is_explicit_and_ignores_later_environment_changes():
+    """kernel choice must not silently follow ambient SLM_* variables.  The
+    environment is parsed once (first use); afterwards only slm_tuning_set / _clear change a knob,
+    and the product sources contain exactly one getenv call (that one-time parse)."""
+    L = _lib.lib()
+    assert L.slm_tuning_clear(None) == 0
+    one = _attn_args_for(1, 1)
+    auto = L.slm_paged_kv_varlen_mha_auto_splits(C.byref(one))
+    os.environ["SLM_ATTN_SPLITS"] = "3"        # too late: must have no effect
+    try:
+        assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(one)) == auto
+    finally:
+        del os.environ["SLM_ATTN_SPLITS"]
+    assert L.slm_tuning_set(b"SLM_ATTN_SPLITS", 3) == 0
+    v, s = C.c_int32(-1), C.c_int32(-1)
+    assert L.slm_tuning_get(b"SLM_ATTN_SPLITS", C.byref(v), C.byref(s)) == 0 and (v.value, s.value) == (3, 1)
+    assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(one)) == 3
+    assert L.slm_tuning_clear(b"SLM_ATTN_SPLITS") == 0
+    assert L.slm_tuning_get(b"SLM_ATTN_SPLITS", C.byref(v), C.byref(s)) == 0 and s.value == 0
+    assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(one)) == auto
+    assert L.slm_tuning_set(b"SLM_NO_SUCH_KNOB", 1) == -1
+    assert L.slm_tuning_set(None, 1) == -1
+    # the python context manager restores what it found
+    from scalellm_amd import kernels
+    with kernels.tuning(SLM_ATTN_SPLITS=5, SLM_W4_SPLITK=2):
+        assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(one)) == 5
+    assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(one)) == auto
+    # a child process that exports the variable BEFORE the library loads does see it (parse-once)
+    code = ("import ctypes as C; from scalellm_amd import _lib; from scalellm_amd._lib import AttnArgs;"
+            "L=_lib.lib(); a=AttnArgs(); a.dtype=1; a.batch_size=1; a.n_tokens=1; a.n_heads=32;"
+            "a.n_kv_heads=8; a.head_dim=128; a.block_size=16; a.max_q_len=1; a.max_kv_len=4096;"
+            "a.k_stride[0]=1024; a.v_stride[0]=1024; print(L.slm_paged_kv_varlen_mha_auto_splits(C.byref(a)))")
+    out = subprocess.check_output(["python", "-c", code], cwd=ROOT, text=True,
+                                  env=dict(os.environ, SLM_ATTN_SPLITS="9"))
+    assert out.strip().endswith("9")
+    # source hygiene: the only getenv in the kernel library is the one-time table fill
+    csrc = os.path.join(ROOT, "scalellm_amd", "csrc")
+    hits = []
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            for i, line in enumerate(open(os.path.join(csrc, f)), 1):
+                if "getenv" in line and not line.lstrip().startswith("//"):
+                    hits.append((f, i))
+    assert hits and all(f == "capi.hip" for f, _ in hits) and len(hits) == 1, hits
+
+
+def _attn_args_for(bs, n_tokens, max_kv=4096):
+    a = AttnArgs()
+    a.dtype, a.batch_size, a.n_tokens = 1, bs, n_tokens
+    a.n_heads, a.n_kv_heads, a.head_dim, a.block_size = 32, 8, 128, 16
+    a.max_q_len, a.max_kv_len = 1, max_kv
+    a.k_stride[0], a.v_stride[0] = 1024, 1024
+    return a
+
+
 def _attn(bs, n_tokens, heads=32, kv_heads=8, d=128, block=16, max_kv=4096, max_q=1, splits=0):
     a = AttnArgs()
     a.dtype, a.batch_size, a.n_tokens = 1, bs, n_tokens
@@ -59,8 +114,7 @@ def _attn(bs, n_tokens, heads=32, kv_heads=8, d=128, block=16, max_kv=4096, max_
 
 def test_split_kv_heuristic_host_side():
     L = _lib.lib()
-    for k in ("SLM_ATTN_SPLITS", "SLM_ATTN_NW", "SLM_ATTN_HGW"):
-        os.environ.pop(k, None)
+    assert L.slm_tuning_clear(None) == 0  # heuristics only: no override knob set
     big = _attn(256, 256)
     assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(big)) == 1
     assert L.slm_paged_kv_varlen_mha_workspace_bytes(C.byref(big)) == 0
@@ -80,8 +134,6 @@ def test_split_kv_heuristic_host_side():
     assert L.slm_paged_kv_varlen_mha_auto_splits(C.byref(forced)) == 7
     # MFMA tile kernel (q_len > 1): split only when the history is long against the chunk AND the
     # tiles cannot put a wave on every SIMD; never for plain prefill (kv ~ q)
-    for k in ("SLM_ATTN_TILE", "SLM_ATTN_TILE_SPLITS"):
-        os.environ.pop(k, None)
     one_chunk = _attn(1, 256, max_q=256, max_kv=8192)       # 8 tiles x 8 heads x 4 waves = 256 waves
     s_chunk = L.slm_paged_kv_varlen_mha_auto_splits(C.byref(one_chunk))
     assert s_chunk == 4
@@ -131,7 +183,7 @@ def test_w4_host_side_planning_and_validation():
     assert L.slm_w4_packed_sz_bytes(4096, 6144, 128) == 32 * 6144 * 4
     g = W4GemmArgs()
     g.M, g.K, g.N, g.lda, g.ldc, g.group_size, g.dtype = 32, 4096, 4096, 4096, 4096, 128, 1
-    os.environ.pop("SLM_W4_SPLITK", None)
+    assert L.slm_tuning_clear(None) == 0
     ws = L.slm_w4a16_gemm_workspace_bytes(C.byref(g))
     assert ws % (32 * 4096 * 4) == 0  # split-K partials: whole [M, N] fp32 slabs (or none)
     g.group_size = 48
@@ -147,8 +199,7 @@ def test_deferred_splitk_reduce_host_side():
     """SLM_W4_DEFER_REDUCE: whether a call defers is a pure function of its argument block, and
     slm_rms_norm_splitk validates before any launch."""
     L = _lib.lib()
-    for k in [k for k in os.environ if k.startswith("SLM_W4_")]:
-        os.environ.pop(k)
+    assert L.slm_tuning_clear(None) == 0
     g = W4GemmArgs()
     g.M, g.K, g.N, g.lda, g.ldc, g.group_size, g.dtype = 256, 14336, 4096, 14336, 4096, 128, 1
     assert L.slm_w4a16_gemm_deferred_splits(C.byref(g)) == 0          # flag not set

@@ -158,12 +158,12 @@ def test_llama3_8b_layer_shapes_awq(M, K, N):
 
 
 @pytest.mark.parametrize("bits", ["bf16", "f16"])
-def test_wave_specialised_kernel_grid(bits, monkeypatch):
+def test_wave_specialised_kernel_grid(bits, tune):
     """The M > 128 kernel (w4_ws.hip: 256 x 128 tiles, producer/consumer waves, LDS-DMA) forced on
     small problems: ragged M (rows clamped, never stored), N not a multiple of 128 (clamped tiles),
     K with 1..7 64-deep chunks past a multiple of the 8-chunk ring (zero-fragment tail), every
     group size, both formats, act-order, bias, split-K (fp32 partials), fp16 and bf16."""
-    monkeypatch.setenv("SLM_W4_MT", "8")
+    tune(SLM_W4_MT=8)
     i = 0
     for M, N, K, gs, fmt, act, sk in (
             (129, 128, 128, 128, "awq", False, 0), (256, 256, 512, 128, "gptq", False, 0),
@@ -171,7 +171,7 @@ def test_wave_specialised_kernel_grid(bits, monkeypatch):
             (257, 384, 2048, -1, "gptq", False, 0), (512, 256, 1024, 128, "awq", False, 2),
             (256, 224, 1792, 128, "gptq", False, 7), (130, 128, 4096, 128, "awq", False, 4)):
         i += 1
-        monkeypatch.setenv("SLM_W4_SPLITK", str(sk))
+        tune(SLM_W4_SPLITK=sk)
         case = helpers.make_quant_case(700 + i, K, N, gs, fmt, bits, act_order=act)
         out, ref = _run_gemm(case, bits, M, bias=(i % 2 == 1), seed=i)
         err = _rel_err(out, ref)
@@ -179,11 +179,11 @@ def test_wave_specialised_kernel_grid(bits, monkeypatch):
 
 
 @pytest.mark.parametrize("bits", ["bf16", "f16"])
-def test_xl_256x256_kernel_grid(bits, monkeypatch):
+def test_xl_256x256_kernel_grid(bits, tune):
     """The symmetric 256 x 256 kernel (w4_xl.hip) forced on small problems: ragged M, N not a
     multiple of 256 (clamped column tiles), K tails past a multiple of the 4-chunk ring, every
     group size, both formats, act-order, bias, split-K."""
-    monkeypatch.setenv("SLM_W4_MT", "16")
+    tune(SLM_W4_MT=16)
     i = 0
     for M, N, K, gs, fmt, act, sk in (
             (129, 256, 128, 128, "awq", False, 0), (256, 512, 512, 128, "gptq", False, 0),
@@ -191,7 +191,7 @@ def test_xl_256x256_kernel_grid(bits, monkeypatch):
             (257, 384, 2048, -1, "gptq", False, 0), (512, 256, 1024, 128, "awq", False, 2),
             (256, 224, 1792, 128, "gptq", False, 7), (130, 288, 4096, 128, "awq", False, 4)):
         i += 1
-        monkeypatch.setenv("SLM_W4_SPLITK", str(sk))
+        tune(SLM_W4_SPLITK=sk)
         case = helpers.make_quant_case(900 + i, K, N, gs, fmt, bits, act_order=act)
         out, ref = _run_gemm(case, bits, M, bias=(i % 2 == 1), seed=i)
         err = _rel_err(out, ref)
@@ -232,12 +232,12 @@ def test_llama3_70b_tp8_rank_shapes_gptq(K, N, act):
 
 
 @pytest.mark.parametrize("bits", ["bf16", "f16"])
-def test_dot2_gemv_kernel_grid(bits, monkeypatch):
+def test_dot2_gemv_kernel_grid(bits, tune):
     """The M <= 4 dot2 GEMV (w4_gemv.hip; default for M = 1, forced here for M = 2..4): every group
     size incl. per-channel (a K slice then holds part of a group: partial activation sums), K not a
     multiple of the 8-way slicing, N not a multiple of the column tiles per workgroup, both formats,
     act-order, bias, rows beyond M never stored."""
-    monkeypatch.setenv("SLM_W4_GEMV", "2")
+    tune(SLM_W4_GEMV=2)
     i = 0
     for M, N, K, gs, fmt, act in (
             (1, 64, 128, 128, "awq", False), (1, 4096, 4096, 128, "awq", False),
@@ -251,17 +251,16 @@ def test_dot2_gemv_kernel_grid(bits, monkeypatch):
         assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, err)
 
 
-@pytest.mark.parametrize("M,K,N,env", [(256, 2048, 28672, {"SLM_W4_MT": "8"}),
-                                       (384, 4096, 4096, {"SLM_W4_MT": "8", "SLM_W4_SPLITK": "4"}),
-                                       (512, 2048, 8192, {"SLM_W4_MT": "16"}),
+@pytest.mark.parametrize("M,K,N,env", [(256, 2048, 28672, {"SLM_W4_MT": 8}),
+                                       (384, 4096, 4096, {"SLM_W4_MT": 8, "SLM_W4_SPLITK": 4}),
+                                       (512, 2048, 8192, {"SLM_W4_MT": 16}),
                                        (32, 4096, 6144, {}), (1, 4096, 6144, {})])
-def test_repeated_launches_are_bit_identical(M, K, N, env, monkeypatch):
+def test_repeated_launches_are_bit_identical(M, K, N, env, tune):
     """The wave-specialised / 256x256 / small-M / GEMV kernels synchronise with bare s_barriers,
     counted vmcnt/lgkmcnt waits and LDS rings: a protocol error would show up as run-to-run
     differences.  30 back-to-back launches (no host sync in between) must agree bit for bit."""
     from scalellm_amd import kernels
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    tune(**env)
     case = helpers.make_quant_case(M + K + N, K, N, 128, "awq", "bf16")
     packed = _pack(case, "bf16")
     g = torch.Generator(device=DEV).manual_seed(M)
@@ -291,24 +290,24 @@ def test_deferred_splitk_reduce_into_rms_norm(M, K, N, dtype):
     w = (1 + 0.1 * torch.randn(N, device=DEV, generator=g)).to(tdt)
     res0 = torch.randn(M, N, device=DEV, dtype=tdt, generator=g)
     c = torch.empty(M, N, device=DEV, dtype=tdt)
-    assert kernels.gptq_gemm(a, packed, c) == 0
+    assert not kernels.gptq_gemm(a, packed, c)
     out_ref, res_ref = torch.empty_like(c), res0.clone()
     kernels.rms_norm(out_ref, c, w, 1e-5, res_ref)
     c2 = torch.full_like(c, float("nan"))  # must not be needed when the reduce is deferred
-    n = kernels.gptq_gemm(a, packed, c2, defer_reduce=True)
+    h = kernels.gptq_gemm(a, packed, c2, defer_reduce=True)
     out, res = torch.empty_like(c), res0.clone()
-    kernels.rms_norm(out, c2, w, 1e-5, res, partial_splits=n)
+    kernels.rms_norm(out, c2, w, 1e-5, res, partials=h)
     torch.cuda.synchronize()
     if (M, K, N) in ((256, 14336, 4096), (32, 14336, 4096)):
-        assert n >= 2, "the down-projection shapes are split over K"
-    if n == 0:
+        assert int(h) >= 2, "the down-projection shapes are split over K"
+    if not h:
         assert torch.equal(c2, c)
     assert torch.equal(out, out_ref) and torch.equal(res, res_ref)
     # without a residual too
     out_b, out_b_ref = torch.empty_like(c), torch.empty_like(c)
     kernels.rms_norm(out_b_ref, c, w, 1e-5)
-    n = kernels.gptq_gemm(a, packed, c2, defer_reduce=True)
-    kernels.rms_norm(out_b, c2, w, 1e-5, partial_splits=n)
+    h = kernels.gptq_gemm(a, packed, c2, defer_reduce=True)
+    kernels.rms_norm(out_b, c2, w, 1e-5, partials=h)
     torch.cuda.synchronize()
     assert torch.equal(out_b, out_b_ref)
 

@@ -17,7 +17,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from scalellm_amd import kernels  # noqa: E402
+from scalellm_amd import _lib, kernels  # noqa: E402
 
 
 def algo_bytes(bs, L, H, HKV, D, B, q_len=1):
@@ -77,7 +77,7 @@ def main():
 
         def run(v):
             for k, val in v.items():
-                os.environ["SLM_ATTN_" + k] = str(val)
+                _lib.check(_lib.lib().slm_tuning_set(("SLM_ATTN_" + k).encode(), int(val)), k)
             kernels.paged_kv_varlen_mha(out, q, kc, vc, q_cu, kv_cu, table, bcu, None, B, 1, L,
                                         D ** -0.5)
 
@@ -121,8 +121,7 @@ def main():
         fout.flush()
         del kc, vc
         torch.cuda.empty_cache()
-    for k in ("U", "NT", "NW", "HGW", "SPLITS"):
-        os.environ.pop("SLM_ATTN_" + k, None)
+    kernels.clear_tuning()
 
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from scalellm_amd import kernels  # noqa: E402
+from scalellm_amd import _lib, kernels  # noqa: E402
 from scalellm_amd.decode import _rand_int4_linear  # noqa: E402
 
 SHAPES = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "down": (14336, 4096),
@@ -58,10 +58,9 @@ def main():
                                 itertools.product([4, 2], [0, 1, 2, 4, 8], [0, 1]) if not (mt == 4 and po)]
             graphs, ok = [], []
             for v in variants:
-                for k_ in [k for k in os.environ if k.startswith("SLM_W4_")]:
-                    del os.environ[k_]  # a variant sets ONLY its own knobs
+                kernels.clear_tuning()  # a variant sets ONLY its own knobs
                 for k_, val in v.items():
-                    os.environ["SLM_W4_" + k_] = str(val)
+                    _lib.check(_lib.lib().slm_tuning_set(("SLM_W4_" + k_).encode(), int(val)), k_)
                 kernels.gptq_gemm(x, packed, c)
                 torch.cuda.synchronize()
                 err = float((c.float() - ref).abs().mean() / ref.abs().mean())
@@ -91,8 +90,7 @@ def main():
                 print(line, flush=True)
                 fout.write(line + "\n")
             fout.flush()
-    for k_ in ("MT", "NTW", "SPLITK", "POST", "PC"):
-        os.environ.pop("SLM_W4_" + k_, None)
+    kernels.clear_tuning()
 
 
 if __name__ == "__main__":
