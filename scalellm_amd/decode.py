@@ -89,8 +89,11 @@ class LlamaDecodeStep:
     def __init__(self, shape: LlamaShape, max_batch_tokens: int, n_blocks: int, block_size: int,
                  parallel_args: Optional[ParallelArgs] = None, quant_method: str = "awq",
                  group_size: int = 128, dtype=torch.bfloat16, device="cuda", seed: int = 0,
-                 kv_fill: str = "none", custom_allreduce=None):
+                 kv_fill: str = "none", custom_allreduce=None, keep_checkpoint: bool = False):
         pa = parallel_args or ParallelArgs()
+        # keep_checkpoint: retain this rank's CHECKPOINT-format tensors (self.ckpt[layer][name]) so a
+        # parity test can rebuild the same model from them on the CPU oracle
+        self.ckpt = [] if keep_checkpoint else None
         # optional custom_allreduce.XgmiAllReduce: the two row-parallel reductions of a layer then
         # run as ONE launch each, fused with the residual add + RMSNorm that follows
         self.custom_ar = custom_allreduce
@@ -138,6 +141,8 @@ class LlamaDecodeStep:
             full = _rand_int4_linear(gen, inter, H, group_size, quant_method, dtype, self.device)
             shard["down"] = _shard_rows(full, quant_method, r * inter // tp, (r + 1) * inter // tp, group_size)
             del full
+            if keep_checkpoint:
+                self.ckpt.append({n: {k: v.clone() for k, v in shard[n].items()} for n in shard})
             for name in ("qkv", "o", "gate_up", "down"):
                 L[name].load_state_dict(shard[name])
                 L[name].verify_loaded_weights()

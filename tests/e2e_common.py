@@ -1,0 +1,119 @@
+"""Shared pieces of the end-to-end logits tests (test infrastructure):
+
+  Sequences    engine-format inputs for a set of sequences, the way Batch::prepare_model_input
+               builds them (engine/batch.cpp:77-270): flattened block table of FIRST-SLOT ids +
+               CSR offsets, new_cache_slots through Sequence::kv_cache_slots
+               (request/sequence.cpp:303-317), q/kv cumulative lengths; prefill, chunked prefill,
+               decode and mixed steps.
+  OracleLlama  a Llama decoder stack as an fp32 forward composed ONLY from oracle.* (the CPU
+               restatement of the reference CPU path; fp32 as llm_engine.cpp:28-31 forces on CPU),
+               over ONE paged KV cache per layer.  tests/test_e2e_oracle_cpu.py pins this
+               composition against HuggingFace LlamaForCausalLM; tests/test_e2e_gpu.py uses it as
+               the reference of the HIP decode path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import oracle
+
+
+def rel_l2(a, b) -> float:
+    return float(np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+
+
+def check_logits(got, ref, tol, what):
+    """Relative L2 error <= tol; greedy ids equal wherever the reference's top-2 margin exceeds 4x
+    the row's largest absolute logit error.  Returns (#rows with equal greedy id, #rows, rel)."""
+    assert np.isfinite(got).all(), what
+    rel = rel_l2(got, ref)
+    assert rel <= tol, f"{what}: relative L2 error of the logits {rel:.3e} > {tol:.0e}"
+    err = np.abs(got - ref).max(axis=-1)
+    srt = np.sort(ref, axis=-1)
+    margin = srt[:, -1] - srt[:, -2]
+    same = got.argmax(-1) == ref.argmax(-1)
+    decisive = margin > 4.0 * err
+    assert same[decisive].all(), f"{what}: greedy id differs although the top-2 margin is decisive"
+    return int(same.sum()), len(same), rel
+
+
+class Sequences:
+    def __init__(self, prompt_lens, max_new, block_size, vocab, seed):
+        rng = np.random.default_rng(seed)
+        self.B = block_size
+        self.tokens = [rng.integers(0, vocab, size=n).tolist() for n in prompt_lens]
+        per = [(n + max_new + block_size - 1) // block_size for n in prompt_lens]
+        self.n_blocks = sum(per) + 3
+        ids = rng.permutation(np.arange(1, self.n_blocks))[:sum(per)]  # unique, shuffled; block 0 unused
+        self.blocks, off = [], 0
+        for nb in per:
+            self.blocks.append(ids[off:off + nb])
+            off += nb
+        self.cached = [0] * len(prompt_lens)
+
+    def inputs(self, new_lens):
+        """Tokens [c, c+n) of every sequence with n > 0 (a sequence with n == 0 sits the step out)."""
+        B = self.B
+        tok, pos, slots, table, bcu, q_cu, kv_cu, rows = [], [], [], [], [0], [0], [0], []
+        for s, n in enumerate(new_lens):
+            if n == 0:
+                continue
+            c0 = self.cached[s]
+            assert c0 + n <= len(self.tokens[s]), "the step needs tokens that were never generated"
+            tok += self.tokens[s][c0:c0 + n]
+            pos += list(range(c0, c0 + n))
+            slots += [int(self.blocks[s][i // B]) * B + i % B for i in range(c0, c0 + n)]
+            nb = (c0 + n + B - 1) // B
+            table += [int(b) * B for b in self.blocks[s][:nb]]   # FIRST-SLOT ids (batch.cpp:206-209)
+            bcu.append(len(table))
+            q_cu.append(q_cu[-1] + n)
+            kv_cu.append(kv_cu[-1] + c0 + n)
+            rows.append(s)
+        i32 = lambda a: np.asarray(a, dtype=np.int32)  # noqa: E731
+        return dict(tokens=i32(tok), positions=i32(pos), slots=i32(slots), table=i32(table),
+                    bcu=i32(bcu), q_cu=i32(q_cu), kv_cu=i32(kv_cu), rows=rows,
+                    max_q=max(n for n in new_lens if n), max_kv=int(np.diff(kv_cu).max()))
+
+    def advance(self, new_lens):
+        self.cached = [c + n for c, n in zip(self.cached, new_lens)]
+
+    def feed(self, inp, next_ids):
+        """Append the greedy token of every row whose sequence has consumed all its tokens."""
+        for row, s in enumerate(inp["rows"]):
+            if self.cached[s] == len(self.tokens[s]):
+                self.tokens[s].append(int(next_ids[row]))
+
+
+class OracleLlama:
+    """layers: list of dicts with dense fp32 [K, N] weights "qkv", "o", "gate_up", "down" (fused
+    q|k|v and gate|up column order) and "in_norm", "post_norm" [hidden]."""
+
+    def __init__(self, layers, final_norm, embed, lm_head, n_heads, n_kv_heads, head_dim, rms_eps,
+                 inv_freq, block_size, n_slots):
+        self.layers, self.final_norm, self.embed, self.lm_head = layers, final_norm, embed, lm_head
+        self.H, self.HKV, self.D, self.eps, self.B = n_heads, n_kv_heads, head_dim, rms_eps, block_size
+        self.inv_freq = np.ascontiguousarray(inv_freq, dtype=np.float32)
+        self.kc = [np.zeros((n_slots, n_kv_heads, head_dim), np.float32) for _ in layers]
+        self.vc = [np.zeros((n_slots, n_kv_heads, head_dim), np.float32) for _ in layers]
+
+    def forward(self, inp):
+        T, H, HKV, D = len(inp["tokens"]), self.H, self.HKV, self.D
+        resid = self.embed[inp["tokens"]].astype(np.float32)
+        normed = oracle.rms_norm(resid, self.layers[0]["in_norm"], self.eps)
+        nq, nkv = H * D, HKV * D
+        for li, W in enumerate(self.layers):
+            qkv = oracle.gemm_f32(normed, W["qkv"])
+            q = oracle.rope(qkv[:, :nq].reshape(T, H, D), inp["positions"], self.inv_freq, D, False)
+            k = oracle.rope(qkv[:, nq:nq + nkv].reshape(T, HKV, D), inp["positions"], self.inv_freq, D, False)
+            v = np.ascontiguousarray(qkv[:, nq + nkv:].reshape(T, HKV, D))
+            oracle.set_kv_cache(inp["slots"], np.ascontiguousarray(k), v, self.kc[li], self.vc[li])
+            a = oracle.paged_attn(q, self.kc[li], self.vc[li], inp["q_cu"], inp["kv_cu"], inp["table"],
+                                  inp["bcu"], self.B, D ** -0.5)
+            resid = resid + oracle.gemm_f32(a.reshape(T, -1), W["o"])
+            normed = oracle.rms_norm(resid, W["post_norm"], self.eps)
+            act = oracle.silu_mul(oracle.gemm_f32(normed, W["gate_up"]))
+            resid = resid + oracle.gemm_f32(act, W["down"])
+            nxt = self.layers[li + 1]["in_norm"] if li + 1 < len(self.layers) else self.final_norm
+            normed = oracle.rms_norm(resid, nxt, self.eps)
+        last = inp["q_cu"][1:] - 1
+        return oracle.gemm_f32(np.ascontiguousarray(normed[last]), self.lm_head)

@@ -155,6 +155,13 @@ def test_llama3_8b_layer_shapes_awq(M, K, N):
                                case["scales"][:, :128], 128)
     got = w[:, :128].view(torch.int16).cpu().numpy().view(np.uint16)
     assert np.array_equal(got, helpers.f32_to_bf16_bits(w_ref))
+    # and the oracle END TO END (checkpoint tensors -> construct_weights -> fp32 matmul,
+    # qlinear_impl.cpp:21-100,171-183) on a subsample of ROWS over ALL N columns: independent of
+    # the library's own dequant and of the vendor GEMM used above
+    rows = sorted({0, M // 2, M - 1})
+    ref_o = oracle.gemm_f32(a[rows].float().cpu().numpy(), _oracle_w(case))
+    err_o = _rel_err(c[rows].float().cpu().numpy(), ref_o)
+    assert err_o < GEMM_TOL["bf16"], err_o
 
 
 @pytest.mark.parametrize("bits", ["bf16", "f16"])
