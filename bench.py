@@ -46,6 +46,15 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
+def _rccl_version():
+    try:
+        if torch.distributed.get_backend() != "nccl":
+            return None
+        return ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001 -- informational only
+        return None
+
+
 def attn_algo_bytes(bs, kv_len, n_heads, n_kv_heads, head_dim, block, q_len=1, esize=2):
     """K+V once, Q+O once, int32 indices once."""
     kv = 2 * bs * kv_len * n_kv_heads * head_dim * esize
@@ -297,15 +306,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--bs", type=int, default=256)
+    ap.add_argument("--model", default="8b", choices=["8b", "70b"], help="8b = Llama-3-8B-shaped, "
+                    "AWQ int4 g128, bs=256 (BASELINE.json metric configuration, configs[1]/[2]); 70b = "
+                    "Llama-3-70B-shaped (in-tree defaults models/meta/llama.h:348-362), GPTQ symmetric "
+                    "int4 g128, bs=128, TP = --gpus (configs[3]; TP=1 fits one MI355X: 35 GB of weights "
+                    "+ 172 GB of KV)")
+    ap.add_argument("--bs", type=int, default=0, help="default 256 (8b) / 128 (70b)")
     ap.add_argument("--seqlen", type=int, default=4096)
     ap.add_argument("--block", type=int, default=16)
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug only: "
                     "a reduced model is NOT the BASELINE config and is flagged in the output)")
-    ap.add_argument("--quant", default="awq", choices=["awq", "gptq"])
+    ap.add_argument("--quant", default="", choices=["", "awq", "gptq"], help="default awq (8b) / "
+                    "gptq with symmetric zero points (70b)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kv-fill", default="randn", choices=["tile", "randn"])
+    ap.add_argument("--kv-fill", default="randn", choices=["tile", "randn", "consistent"],
+                    help="consistent: every rank draws the full-head history and keeps its shard, so "
+                    "TP=N and TP=1 decode the same model state (tests compare their tokens)")
     ap.add_argument("--advance", action="store_true", help="include the device-side input build "
                     "(slm_decode_advance, SURVEY 8f f4) in the step: every replay appends one token "
                     "per sequence, so kv_len grows by one per step from --seqlen")
@@ -333,11 +350,13 @@ def main():
         pa = ParallelArgs(rank=0, world_size=args.simulate_tp,
                           process_group=LocalShardProcessGroup(args.simulate_tp))
 
-    shape = LlamaShape.llama3_8b()
+    shape = LlamaShape.llama3_70b() if args.model == "70b" else LlamaShape.llama3_8b()
+    quant = args.quant or ("gptq" if args.model == "70b" else "awq")
+    gptq_sym = args.model == "70b"  # BASELINE configs[3]: GPTQ symmetric (zero = 8), group 128
     reduced = False
     if args.layers > 0 and args.layers != shape.n_layers:
         shape.n_layers, reduced = args.layers, True
-    bs, L, B = args.bs, args.seqlen, args.block
+    bs, L, B = args.bs or (128 if args.model == "70b" else 256), args.seqlen, args.block
     shape.max_position = max(shape.max_position, L + 8 + (args.steps + 2 * args.warmup + 16 if args.advance else 0))
     spare = ((args.steps + 2 * args.warmup + 8) // B + 2) if args.advance else 0
     tokens, positions, params, n_blocks = make_decode_inputs(bs, L, B, device, seed=1, vocab=shape.vocab,
@@ -355,9 +374,9 @@ def main():
         custom_ar = try_create_xgmi_allreduce(
             pg.rank, pg.world_size, bs, shape.hidden, torch.bfloat16, device,
             log=lambda m: print(f"[bench] {m}", file=sys.stderr))
-    model = LlamaDecodeStep(shape, bs, n_blocks, B, pa, quant_method=args.quant, group_size=128,
+    model = LlamaDecodeStep(shape, bs, n_blocks, B, pa, quant_method=quant, group_size=128,
                             dtype=torch.bfloat16, device=device, seed=0, kv_fill=args.kv_fill,
-                            custom_allreduce=custom_ar)
+                            custom_allreduce=custom_ar, gptq_sym=gptq_sym)
     model.reserve_workspaces(bs, L)
     torch.cuda.synchronize()
     t_init = time.perf_counter() - t_init
@@ -374,8 +393,12 @@ def main():
     if world > 1:  # line the ranks up (model init skews them by seconds) before the first collective
         torch.cuda.synchronize()
         torch.distributed.barrier()
-    for _ in range(max(args.warmup, 1)):
+    first_tokens = None
+    for i in range(max(args.warmup, 1)):
         step()
+        if i == 0:  # the first step's greedy ids: a TP=N run must reproduce the TP=1 run's
+            torch.cuda.synchronize()
+            first_tokens = static_tokens[:16].tolist()
     torch.cuda.synchronize()
 
     graph = None
@@ -454,18 +477,22 @@ def main():
     out = None
     if rank == 0:
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        # the CPU baseline belongs to the metric configuration (8b, AWQ); other models report null
+        if world == 1 and not args.no_cpu_baseline and args.model == "8b" and quant == "awq":
             cpu = cpu_baseline(model, tokens, params, sample_seqs=16, kv_len=L, block=B)
+        mname = "Llama-3-70B" if args.model == "70b" else "Llama-3-8B"
         out = {
-            "metric": "decode tokens/s (Llama-3-8B-shaped step, bs=256, seq=4k; paged-attention "
+            "metric": f"decode tokens/s ({mname}-shaped step, bs={bs}, seq={L // 1024}k; paged-attention "
                       "HBM roofline + int4-GEMM TFLOP/s alongside)",
             "value": round(tok_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16 (int4 weights, fp32 accumulate)",
             "data": "synthetic (seeded random weights, KV history and tokens)",
-            "config": {"workload": f"llama3-8b-shaped decode step: bs={bs}, kv_len={L}, q_len=1, "
-                                   f"block_size={B}, {shape.n_layers} layers, {args.quant} int4 g128 "
+            "config": {"workload": f"llama3-{args.model}-shaped decode step: bs={bs}, kv_len={L}, q_len=1, "
+                                   f"block_size={B}, {shape.n_layers} layers, {quant}"
+                                   f"{' (symmetric)' if gptq_sym and quant == 'gptq' else ''} int4 g128 "
                                    f"linears, bf16 KV cache, greedy",
+                       "model": args.model,
                        "global_batch": bs, "seq_len": L,
                        "parallelism": f"tp{world}" if world > 1 else "single-gpu",
                        "hip_graph": graph is not None, "reduced_model": reduced,
@@ -473,7 +500,17 @@ def main():
                                                "xgmi two-shot all-reduce fused with residual+rmsnorm "
                                                "(embedding gather and greedy sampling exchange through "
                                                "the same kernel: no RCCL in the step)"
-                                               if custom_ar is not None else "rccl all-reduce + rms_norm"),
+                                               if custom_ar is not None else
+                                               ("rccl" if torch.distributed.get_backend() == "nccl"
+                                                else torch.distributed.get_backend())
+                                               + " all-reduce + rms_norm"),
+                       "collectives": (None if world == 1 else
+                                       {"backend": torch.distributed.get_backend(),
+                                        "ranks": torch.distributed.get_world_size(),
+                                        "rccl_version": _rccl_version(),
+                                        "in_step": "none (fused xGMI kernel)" if custom_ar is not None
+                                        else "all-reduce x2 per layer + all-gather (embedding, lm_head)"}),
+                       "first_step_tokens": first_tokens,
                        "device_side_input_advance": bool(args.advance),
                        "simulated_tp_rank0_only": args.simulate_tp if args.simulate_tp > 1 else None,
                        "kv_cache_gib_per_gpu": round(2 * n_blocks * B * model.n_kv_heads * shape.head_dim

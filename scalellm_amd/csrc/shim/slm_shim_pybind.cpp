@@ -45,6 +45,44 @@ PYBIND11_MODULE(_slm_shim, m) {
       .def("forward", &slm::W4Linear::forward, py::arg("input"), py::arg("bias") = std::nullopt,
            py::arg("out") = std::nullopt)
       .def("dequantize", &slm::W4Linear::dequantize);
+  m.def("process_group_test", [](int n_devices) {
+    // The reference's ProcessGroupTest (src/model_parallel/process_group_test.cpp:48-171) in its
+    // own shape: ONE process, one communicator per GPU created together (ncclCommInitAll), one
+    // host thread + stream per rank.  n_devices <= 0 means every visible GPU, so the same test
+    // widens from world 1 on a 1-GPU box to world 8 on a full node.  Returns, per rank, whether
+    // all-reduce (SUM of rank+1 == n(n+1)/2, exact) and both all-gather forms are correct.
+    py::gil_scoped_release nogil;
+    int n = n_devices > 0 ? n_devices : static_cast<int>(torch::cuda::device_count());
+    std::vector<torch::Device> devs;
+    for (int i = 0; i < n; ++i) devs.emplace_back(torch::kCUDA, i);
+    auto pgs = slm::ProcessGroupRCCL::create_process_groups(devs);
+    std::vector<int> ok(n, 0);
+    std::vector<std::thread> threads;
+    for (int r = 0; r < n; ++r)
+      threads.emplace_back([&, r]() {
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(devs[r]);
+        auto opt = torch::dtype(torch::kHalf).device(devs[r]);
+        for (int rep = 0; rep < 3; ++rep) {   // repeated: a communicator must survive reuse
+          auto t = torch::full({10, 10}, static_cast<float>(r + 1), opt);
+          pgs[r]->allreduce(t);
+          const bool ar = torch::equal(t.cpu(), torch::full({10, 10}, n * (n + 1) / 2.0f, torch::kHalf));
+          auto mine = torch::full({4, 8}, static_cast<float>(r + 1), opt);
+          auto flat = torch::zeros({n * 4, 8}, opt);
+          pgs[r]->allgather(mine, flat);
+          std::vector<torch::Tensor> outs;
+          for (int q = 0; q < n; ++q) outs.push_back(torch::zeros({4, 8}, opt));
+          pgs[r]->allgather(mine, outs);
+          bool ag = true;
+          for (int q = 0; q < n; ++q) {
+            const auto want = torch::full({4, 8}, static_cast<float>(q + 1), torch::kHalf);
+            ag = ag && torch::equal(flat.narrow(0, 4 * q, 4).cpu(), want) && torch::equal(outs[q].cpu(), want);
+          }
+          ok[r] = (rep == 0 ? 1 : ok[r]) && ar && ag && pgs[r]->rank() == r && pgs[r]->world_size() == n;
+        }
+      });
+    for (auto& t : threads) t.join();
+    return std::make_pair(n, ok);
+  });
   m.def("process_group_selftest", [](int device_index) {
     // Worker::process_group_test (engine/worker.cpp:111-123) on the GPUs visible here
     std::vector<torch::Device> devs{torch::Device(torch::kCUDA, device_index)};

@@ -52,8 +52,10 @@ class LlamaShape:
                           n_layers=2, vocab=1024, max_position=512)
 
 
-def _rand_int4_linear(gen, K, N, group_size, fmt, dtype, device):
-    """Random layer in CHECKPOINT format (AWQ [K,N/8] / GPTQ [K/8,N]); random bits = uniform nibbles."""
+def _rand_int4_linear(gen, K, N, group_size, fmt, dtype, device, sym=False):
+    """Random layer in CHECKPOINT format (AWQ [K,N/8] / GPTQ [K/8,N]); random bits = uniform nibbles.
+    sym: GPTQ symmetric quantisation -- every stored zero point is 7 (zero = stored + 1 = 8,
+    qlinear_impl.cpp:45), what `sym: true` GPTQ checkpoints carry."""
     G = K // group_size
     if fmt == "awq":
         qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, (K, N // 8), device=device, generator=gen,
@@ -63,6 +65,8 @@ def _rand_int4_linear(gen, K, N, group_size, fmt, dtype, device):
                                 dtype=torch.int64).to(torch.int32)
     qzeros = torch.randint(-2 ** 31, 2 ** 31 - 1, (G, N // 8), device=device, generator=gen,
                            dtype=torch.int64).to(torch.int32)
+    if sym:
+        qzeros.fill_(0x77777777)
     scales = (torch.rand(G, N, device=device, generator=gen) * 0.006 + 0.002).to(dtype)
     return {"qweight": qweight, "qzeros": qzeros, "scales": scales}
 
@@ -89,7 +93,8 @@ class LlamaDecodeStep:
     def __init__(self, shape: LlamaShape, max_batch_tokens: int, n_blocks: int, block_size: int,
                  parallel_args: Optional[ParallelArgs] = None, quant_method: str = "awq",
                  group_size: int = 128, dtype=torch.bfloat16, device="cuda", seed: int = 0,
-                 kv_fill: str = "none", custom_allreduce=None, keep_checkpoint: bool = False):
+                 kv_fill: str = "none", custom_allreduce=None, keep_checkpoint: bool = False,
+                 gptq_sym: bool = False):
         pa = parallel_args or ParallelArgs()
         # keep_checkpoint: retain this rank's CHECKPOINT-format tensors (self.ckpt[layer][name]) so a
         # parity test can rebuild the same model from them on the CPU oracle
@@ -126,19 +131,23 @@ class LlamaDecodeStep:
             L["o"] = RowParallelQLinear(q_full, H, False, qa, True, pa, dtype, self.device)
             L["gate_up"] = ColumnParallelQLinear(H, 2 * inter, False, qa, False, pa, dtype, self.device)
             L["down"] = RowParallelQLinear(inter, H, False, qa, True, pa, dtype, self.device)
-            full = _rand_int4_linear(gen, H, q_full + 2 * kv_full, group_size, quant_method, dtype, self.device)
+            full = _rand_int4_linear(gen, H, q_full + 2 * kv_full, group_size, quant_method, dtype, self.device,
+                                     sym=gptq_sym and quant_method == "gptq")
             shard = {
                 "qkv": _shard_cols(full, quant_method, [
                     (r * nh * D, (r + 1) * nh * D),
                     (q_full + kv_head0 * D, q_full + (kv_head0 + nkv) * D),
                     (q_full + kv_full + kv_head0 * D, q_full + kv_full + (kv_head0 + nkv) * D)])}
-            full = _rand_int4_linear(gen, q_full, H, group_size, quant_method, dtype, self.device)
+            full = _rand_int4_linear(gen, q_full, H, group_size, quant_method, dtype, self.device,
+                                     sym=gptq_sym and quant_method == "gptq")
             shard["o"] = _shard_rows(full, quant_method, r * nh * D, (r + 1) * nh * D, group_size)
-            full = _rand_int4_linear(gen, H, 2 * inter, group_size, quant_method, dtype, self.device)
+            full = _rand_int4_linear(gen, H, 2 * inter, group_size, quant_method, dtype, self.device,
+                                     sym=gptq_sym and quant_method == "gptq")
             shard["gate_up"] = _shard_cols(full, quant_method, [
                 (r * inter // tp, (r + 1) * inter // tp),
                 (inter + r * inter // tp, inter + (r + 1) * inter // tp)])
-            full = _rand_int4_linear(gen, inter, H, group_size, quant_method, dtype, self.device)
+            full = _rand_int4_linear(gen, inter, H, group_size, quant_method, dtype, self.device,
+                                     sym=gptq_sym and quant_method == "gptq")
             shard["down"] = _shard_rows(full, quant_method, r * inter // tp, (r + 1) * inter // tp, group_size)
             del full
             if keep_checkpoint:

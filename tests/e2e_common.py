@@ -89,31 +89,55 @@ class OracleLlama:
     q|k|v and gate|up column order) and "in_norm", "post_norm" [hidden]."""
 
     def __init__(self, layers, final_norm, embed, lm_head, n_heads, n_kv_heads, head_dim, rms_eps,
-                 inv_freq, block_size, n_slots):
+                 inv_freq, block_size, n_slots, storage=None):
+        """storage=None: pure fp32 (the reference CPU path).  storage="bf16": the same arithmetic
+        with every tensor the GPU path STORES (activations between ops, residual stream, KV cache,
+        logits) rounded to bf16 at the point it is stored -- the "storage twin": what is left
+        between it and the HIP path is accumulation order and fast-math, not precision of storage."""
+        self.storage = storage
         self.layers, self.final_norm, self.embed, self.lm_head = layers, final_norm, embed, lm_head
         self.H, self.HKV, self.D, self.eps, self.B = n_heads, n_kv_heads, head_dim, rms_eps, block_size
         self.inv_freq = np.ascontiguousarray(inv_freq, dtype=np.float32)
         self.kc = [np.zeros((n_slots, n_kv_heads, head_dim), np.float32) for _ in layers]
         self.vc = [np.zeros((n_slots, n_kv_heads, head_dim), np.float32) for _ in layers]
 
+    def _r(self, x):
+        if self.storage is None:
+            return x
+        from tests import helpers
+        return helpers.bf16_bits_to_f32(helpers.f32_to_bf16_bits(x)).reshape(x.shape)
+
+    def _norm(self, h, w):
+        if self.storage is None:
+            return oracle.rms_norm(h, w, self.eps)
+        # slm_rms_norm: y = T(T(h * rsqrt(mean h^2 + eps)) * w) on the UNROUNDED fp32 h
+        # (normalization.h:27-29 rounds the normalised value to T before the weight)
+        rs = (1.0 / np.sqrt((h.astype(np.float64) ** 2).mean(-1, keepdims=True) + self.eps)).astype(np.float32)
+        return self._r(self._r(h * rs) * w)
+
     def forward(self, inp):
         T, H, HKV, D = len(inp["tokens"]), self.H, self.HKV, self.D
+        r = self._r
         resid = self.embed[inp["tokens"]].astype(np.float32)
-        normed = oracle.rms_norm(resid, self.layers[0]["in_norm"], self.eps)
+        normed = self._norm(resid, self.layers[0]["in_norm"])
         nq, nkv = H * D, HKV * D
         for li, W in enumerate(self.layers):
-            qkv = oracle.gemm_f32(normed, W["qkv"])
-            q = oracle.rope(qkv[:, :nq].reshape(T, H, D), inp["positions"], self.inv_freq, D, False)
-            k = oracle.rope(qkv[:, nq:nq + nkv].reshape(T, HKV, D), inp["positions"], self.inv_freq, D, False)
+            qkv = r(oracle.gemm_f32(normed, W["qkv"]))
+            q = r(oracle.rope(qkv[:, :nq].reshape(T, H, D), inp["positions"], self.inv_freq, D, False))
+            k = r(oracle.rope(qkv[:, nq:nq + nkv].reshape(T, HKV, D), inp["positions"], self.inv_freq, D, False))
             v = np.ascontiguousarray(qkv[:, nq + nkv:].reshape(T, HKV, D))
             oracle.set_kv_cache(inp["slots"], np.ascontiguousarray(k), v, self.kc[li], self.vc[li])
-            a = oracle.paged_attn(q, self.kc[li], self.vc[li], inp["q_cu"], inp["kv_cu"], inp["table"],
-                                  inp["bcu"], self.B, D ** -0.5)
-            resid = resid + oracle.gemm_f32(a.reshape(T, -1), W["o"])
-            normed = oracle.rms_norm(resid, W["post_norm"], self.eps)
-            act = oracle.silu_mul(oracle.gemm_f32(normed, W["gate_up"]))
-            resid = resid + oracle.gemm_f32(act, W["down"])
+            a = r(oracle.paged_attn(q, self.kc[li], self.vc[li], inp["q_cu"], inp["kv_cu"], inp["table"],
+                                    inp["bcu"], self.B, D ** -0.5))
+            # rms_norm_residual (normalization.h:42-52): h = x + residual in fp32, residual = T(h),
+            # the norm reads the fp32 h
+            h = r(oracle.gemm_f32(a.reshape(T, -1), W["o"])) + resid
+            resid = r(h)
+            normed = self._norm(h, W["post_norm"])
+            act = r(oracle.silu_mul(r(oracle.gemm_f32(normed, W["gate_up"]))))
+            h = r(oracle.gemm_f32(act, W["down"])) + resid
+            resid = r(h)
             nxt = self.layers[li + 1]["in_norm"] if li + 1 < len(self.layers) else self.final_norm
-            normed = oracle.rms_norm(resid, nxt, self.eps)
+            normed = self._norm(h, nxt)
         last = inp["q_cu"][1:] - 1
-        return oracle.gemm_f32(np.ascontiguousarray(normed[last]), self.lm_head)
+        return r(oracle.gemm_f32(np.ascontiguousarray(normed[last]), self.lm_head))

@@ -14,7 +14,14 @@ stated fp tolerance").
     RoPE), attention + KV append through scalellm_amd.kernels.*, against HuggingFace fp32 logits
     (the prompt shapes of examples/cpu_offline_inference.py:4-9).
 
-Stated tolerance: relative L2 error of the logits per step <= 2e-2 for the bf16 Llama stacks;
+Stated tolerance (relative L2 error of the logits, per step), Llama bf16 stacks, TWO references:
+  * the pure-fp32 oracle forward (= the reference CPU path): <= 3e-2.  This bound is the price of
+    bf16 STORAGE, not of the kernels: every activation, the residual stream and the KV cache are
+    rounded to 8 mantissa bits between ops (measured 1.2-2.2e-2 on the 2-layer 4096-wide stack,
+    where random weights make the attention logits ~3.6 sigma wide and amplify it);
+  * the same oracle forward with exactly those storage roundings emulated (OracleLlama(storage=
+    "bf16")): <= 6e-3 -- what is left is accumulation order, P rounded to bf16 before P.V and
+    fast-math exp/rcp: this is the bound that pins the HIP kernels.
 GPT-2 (12 layers, the whole residual stream in the 16-bit dtype) <= 3e-2 bf16 / 4e-3 fp16; greedy
 token ids identical wherever the reference's top-2 margin exceeds 4x the largest absolute logit
 error of that row (a smaller margin is a coin flip at any 16-bit precision), and in >= 90 % of
@@ -41,7 +48,7 @@ def _params(inp):
                             kv_max_seq_len=inp["max_kv"]))
 
 
-def _oracle_twin(model, quant_method, group_size):
+def _oracle_twin(model, quant_method, group_size, storage=None):
     """The same model as a LlamaDecodeStep(keep_checkpoint=True), rebuilt on the CPU from the
     CHECKPOINT-format int4 tensors: oracle.{awq,gptq}_dequant = construct_weights
     (qlinear_impl.cpp:21-100), then fp32 matmul (:171-183)."""
@@ -62,7 +69,7 @@ def _oracle_twin(model, quant_method, group_size):
     inv_freq = (1.0 / (s.rope_theta ** (np.arange(0, D, 2, dtype=np.float32) / D))).astype(np.float32)
     return OracleLlama(layers, f(model.final_norm), f(model.embed), f(model.lm_head), s.n_heads,
                        s.n_kv_heads, D, s.rms_eps, inv_freq, model.block_size,
-                       model.layers[0]["kv"].key_cache.size(0))
+                       model.layers[0]["kv"].key_cache.size(0), storage=storage)
 
 
 def _llama_cases():
@@ -89,8 +96,10 @@ def test_llama_prefill_then_decode_logits_match_oracle(name):
     steps += [[1] * len(prompt_lens)] * n_decode
     model = LlamaDecodeStep(shape, sum(prompt_lens) + 8, seqs.n_blocks, B, quant_method=quant,
                             group_size=gs, dtype=torch.bfloat16, device=DEV, seed=3, keep_checkpoint=True)
-    ref_model = _oracle_twin(model, quant, gs)
+    ref_model = _oracle_twin(model, quant, gs)                       # the reference CPU path: fp32
+    twin_model = _oracle_twin(model, quant, gs, storage="bf16")      # + the GPU path's storage roundings
     agree = total = 0
+    rels = []
     for si, new_lens in enumerate(steps):
         inp = seqs.inputs(new_lens)
         tokens, positions, params = _params(inp)
@@ -98,12 +107,17 @@ def test_llama_prefill_then_decode_logits_match_oracle(name):
         torch.cuda.synchronize()
         got = logits.float().cpu().numpy()
         ref = ref_model.forward(inp)
-        a, n, rel = check_logits(got, ref, 2e-2, f"{name} step {si} (q_lens {new_lens})")
+        a, n, rel = check_logits(got, ref, 3e-2, f"{name} step {si} (q_lens {new_lens}) vs fp32 oracle")
         agree, total = agree + a, total + n
+        _, _, rel_t = check_logits(got, twin_model.forward(inp), 6e-3,
+                                   f"{name} step {si} (q_lens {new_lens}) vs bf16-storage twin")
+        rels.append((round(rel, 5), round(rel_t, 5)))
         seqs.advance(new_lens)
         # teacher forcing with the GPU's greedy token: both paths see the same next input, so
         # every step is compared on its own (a near-tie flip must not cascade)
         seqs.feed(inp, got.argmax(-1))
+    print(f"[e2e] {name}: per-step relative L2 error (vs fp32 oracle, vs bf16-storage twin): {rels}; "
+          f"greedy ids equal on {agree}/{total} rows")
     assert agree >= 0.9 * total, f"{name}: greedy ids agree on only {agree}/{total} rows"
 
 

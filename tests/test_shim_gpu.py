@@ -111,6 +111,18 @@ def test_shim_process_group_rccl_single_gpu(shim):
     assert s == 100.0 and g == 100.0
 
 
+def test_shim_process_group_rccl_thread_per_gpu_all_visible_gpus(shim):
+    """The reference's ProcessGroupTest (process_group_test.cpp:48-171: world 1, 2, 4, 8; all-reduce
+    == sequential sum, all-gather in both forms) in the reference's own shape -- one process, one
+    communicator per GPU from ncclCommInitAll, one host thread per rank -- at world = EVERY GPU
+    this box has: 1 here on a single-GPU box, 8 automatically on a full node (where the sub-worlds
+    2 and 4 run as well)."""
+    n_gpu = torch.cuda.device_count()
+    for world in sorted({w for w in (1, 2, 4, 8) if w <= n_gpu} | {n_gpu}):
+        n, ok = shim.process_group_test(world)
+        assert n == world and ok == [1] * world, (world, ok)
+
+
 # world = 2 only, in a FRESH process: ranks that share ONE device need their kernels co-resident,
 # and streams of a process that has already created many (as this test session has) may be
 # multiplexed onto the same hardware queue and then serialise -- an artefact of testing on one GPU
