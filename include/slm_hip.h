@@ -169,6 +169,17 @@ SLM_API int slm_w4_prepack(int32_t format,            /* slm_w4_format          
                            const int32_t* perm,       /* [K] sorted-row -> ckpt-row, or NULL */
                            int64_t K, int64_t N, int64_t group_size, int32_t dtype,
                            void* wq_out, void* sz_out, void* stream);
+/* The two halves of slm_w4_prepack, for callers that hold the weights and the scale / zero-point
+ * tensors at different times -- marlin::gptq_repack / awq_repack take q_weight alone
+ * (marlin.h:27-35) and marlin::gptq_gemm takes scales / zeros per call (marlin.h:17-25):
+ *   weights: qweight (+ perm) -> wq_out  [K*N/8 uint32, this library's layout];
+ *   sz     : scales (+ qzeros) -> sz_out [G*N uint32].  qzeros == NULL means symmetric
+ *            quantisation, zero = 8 (what Marlin's has_zp = false means for 4 bits). */
+SLM_API int slm_w4_prepack_weights(int32_t format, const int32_t* qweight, const int32_t* perm,
+                                   int64_t K, int64_t N, void* wq_out, void* stream);
+SLM_API int slm_w4_prepack_sz(int32_t format, const int32_t* qzeros /* or NULL */, const void* scales,
+                              int64_t K, int64_t N, int64_t group_size, int32_t dtype, void* sz_out,
+                              void* stream);
 
 /* ========================================================================== */
 /* 4. int4-weight x fp16/bf16-activation GEMM  C[M,N] = A[M,K] . dequant(W)   */

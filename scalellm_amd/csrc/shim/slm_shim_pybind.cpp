@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <thread>
 
+#include "slm_qlinear_hip.h"
 #include "slm_torch_shim.h"
 
 namespace py = pybind11;
@@ -39,6 +40,67 @@ PYBIND11_MODULE(_slm_shim, m) {
   });
   m.def("silu_and_mul",
         [](torch::Tensor out, torch::Tensor input) { llm::kernel::silu_and_mul(out, input); });
+  m.def("silu_with_mul", &llm::kernel::silu_with_mul, py::arg("input"));
+  // scalellm/csrc/kernels.cu:24-54, verbatim names and keyword arguments: `_C.kernels`
+  m.def("marlin_gemm",
+        [](const torch::Tensor& A, const torch::Tensor& B, torch::Tensor C, const torch::Tensor& scales,
+           const torch::Tensor& zeros, const torch::Tensor& g_idx, const torch::Tensor& perm,
+           torch::Tensor workspace, int num_bits, bool is_k_full, bool has_zp, bool use_fp32_reduce) {
+          marlin::gptq_gemm(A, B, C, scales, zeros, g_idx, perm, workspace, num_bits, is_k_full, has_zp,
+                            use_fp32_reduce);
+        },
+        "Marlin GPTQ GEMM", py::arg("A"), py::arg("B"), py::arg("C"), py::arg("scales"), py::arg("zeros"),
+        py::arg("g_idx"), py::arg("perm"), py::arg("workspace"), py::arg("num_bits"), py::arg("is_k_full"),
+        py::arg("has_zp"), py::arg("use_fp32_reduce"));
+  m.def("marlin_gptq_repack",
+        [](const torch::Tensor& q_weight, const torch::Tensor& perm, torch::Tensor out, int64_t num_bits) {
+          marlin::gptq_repack(q_weight, perm, out, num_bits);
+        },
+        "Marlin GPTQ repack", py::arg("q_weight"), py::arg("perm"), py::arg("out"), py::arg("num_bits"));
+  m.def("marlin_awq_repack",
+        [](const torch::Tensor& q_weight, torch::Tensor out, int64_t num_bits) {
+          marlin::awq_repack(q_weight, out, num_bits);
+        },
+        "Marlin AWQ repack", py::arg("q_weight"), py::arg("out"), py::arg("num_bits"));
+  // the layer boundary: ParallelLinearImpl (parallel_linear.h:17-37) through its factory
+  py::class_<slm::ParallelLinearImpl, std::shared_ptr<slm::ParallelLinearImpl>>(m, "ParallelLinearImpl")
+      .def("forward", &slm::ParallelLinearImpl::forward)
+      .def("load_state_dict",
+           [](slm::ParallelLinearImpl& self, std::unordered_map<std::string, torch::Tensor> sd) {
+             self.load_state_dict(slm::StateDict(std::move(sd)));
+           })
+      .def("load_state_dict_fused",
+           [](slm::ParallelLinearImpl& self, std::unordered_map<std::string, torch::Tensor> sd,
+              const std::vector<std::string>& prefixes) {
+             self.load_state_dict(slm::StateDict(std::move(sd)), prefixes);
+           })
+      .def("verify_loaded_weights", &slm::ParallelLinearImpl::verify_loaded_weights, py::arg("prefix") = "");
+  auto make_args = [](const std::string& method, int64_t bits, int64_t group_size, bool desc_act, bool is_sym,
+                      bool zero_point) {
+    slm::QuantArgs qa;
+    qa.quant_method(method).bits(bits).group_size(group_size).desc_act(desc_act).is_sym(is_sym).zero_point(zero_point);
+    return qa;
+  };
+  m.def("create_column_parallel_qlinear",
+        [make_args](int64_t in_features, int64_t out_features, bool bias, bool gather_output,
+                    const std::string& quant_method, int64_t bits, int64_t group_size, bool desc_act, bool is_sym,
+                    bool zero_point, int rank, int world_size, torch::ScalarType dtype, int device_index) {
+          return slm::create_column_parallel_qlinear(
+              in_features, out_features, bias, gather_output,
+              make_args(quant_method, bits, group_size, desc_act, is_sym, zero_point),
+              slm::ParallelArgs(rank, world_size, nullptr),
+              torch::dtype(dtype).device(torch::Device(torch::kCUDA, device_index)));
+        });
+  m.def("create_row_parallel_qlinear",
+        [make_args](int64_t in_features, int64_t out_features, bool bias, bool input_is_parallelized,
+                    const std::string& quant_method, int64_t bits, int64_t group_size, bool desc_act, bool is_sym,
+                    bool zero_point, int rank, int world_size, torch::ScalarType dtype, int device_index) {
+          return slm::create_row_parallel_qlinear(
+              in_features, out_features, bias, input_is_parallelized,
+              make_args(quant_method, bits, group_size, desc_act, is_sym, zero_point),
+              slm::ParallelArgs(rank, world_size, nullptr),
+              torch::dtype(dtype).device(torch::Device(torch::kCUDA, device_index)));
+        });
   py::class_<slm::W4Linear>(m, "W4Linear")
       .def(py::init<const std::string&, const torch::Tensor&, const torch::Tensor&,
                     const torch::Tensor&, const std::optional<torch::Tensor>&, int64_t>())

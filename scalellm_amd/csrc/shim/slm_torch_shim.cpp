@@ -211,8 +211,158 @@ void silu_and_mul(torch::Tensor& out, torch::Tensor input) {
         "slm_silu_mul");
 }
 
+torch::Tensor silu_with_mul(torch::Tensor input) {
+  // activation_kernels.cu:84-ff: out [..., d] = silu(input[..., :d]) * input[..., d:]
+  TORCH_CHECK(input.is_contiguous() && input.size(-1) % 2 == 0);
+  auto sizes = input.sizes().vec();
+  sizes.back() /= 2;
+  auto out = torch::empty(sizes, input.options());
+  silu_and_mul(out, input);
+  return out;
+}
+
 }  // namespace kernel
 }  // namespace llm
+
+// ---------------------------------------------------------------------------------------------
+// marlin:: -- the reference's int4 kernel boundary (marlin.h:17-37), see slm_torch_shim.h
+// ---------------------------------------------------------------------------------------------
+namespace marlin {
+namespace {
+struct SzKey {
+  const void* scales;
+  const void* zeros;
+  int64_t version, K, N;
+  bool operator==(const SzKey& o) const {
+    return scales == o.scales && zeros == o.zeros && version == o.version && K == o.K && N == o.N;
+  }
+};
+struct SzKeyHash {
+  size_t operator()(const SzKey& k) const {
+    return std::hash<const void*>()(k.scales) ^ (std::hash<const void*>()(k.zeros) << 1) ^
+           std::hash<int64_t>()(k.version * 1315423911 + k.K * 31 + k.N);
+  }
+};
+// gptq_gemm receives scales / zeros on EVERY call (they are layer parameters, constant after
+// load); the kernels want them fused into one {scale, magic + zero} word per (group, column).
+// Built once per (scales, zeros) pair on first use -- during the engine's warm-up, before graph
+// capture -- and kept for the life of the process; steady state is a hash lookup.
+// An entry is valid only while the storages it was built from are alive: a freed parameter's
+// address can be handed to a different tensor by the caching allocator.
+struct SzEntry {
+  torch::Tensor sz;
+  c10::weak_intrusive_ptr<c10::StorageImpl> scales_st, zeros_st;
+};
+std::mutex g_sz_mu;
+std::unordered_map<SzKey, SzEntry, SzKeyHash> g_sz_cache;
+
+bool same_live_storage(const c10::weak_intrusive_ptr<c10::StorageImpl>& w, const torch::Tensor& t) {
+  const auto alive = w.lock();
+  return alive && alive.get() == t.storage().unsafeGetStorageImpl();
+}
+
+void check_repack_args(const torch::Tensor& q_weight, const torch::Tensor& out, int64_t num_bits, int64_t K,
+                       int64_t N) {
+  TORCH_CHECK(num_bits == 4, "only 4-bit weights are supported on the HIP int4 path, got ", num_bits);
+  TORCH_CHECK(q_weight.is_cuda() && q_weight.is_contiguous() && q_weight.scalar_type() == torch::kInt);
+  TORCH_CHECK(out.is_cuda() && out.is_contiguous() && out.scalar_type() == torch::kInt &&
+              out.numel() == K * N / 8, "out must be int32 [K/16, N*16/8]");
+  TORCH_CHECK(slm_w4_packed_weight_bytes(K, N) == static_cast<size_t>(K * N / 2),
+              "unsupported int4 shape K=", K, " N=", N, " (need K % 64 == 0, N % 32 == 0)");
+}
+}  // namespace
+
+void gptq_repack(const torch::Tensor& q_weight, const torch::Tensor& perm, torch::Tensor& out,
+                 int64_t num_bits) {
+  const int64_t K = q_weight.size(0) * 8, N = q_weight.size(1);
+  check_repack_args(q_weight, out, num_bits, K, N);
+  const bool has_perm = perm.defined() && perm.numel() > 0;
+  if (has_perm)
+    TORCH_CHECK(perm.numel() == K && perm.scalar_type() == torch::kInt && perm.is_contiguous(),
+                "perm must be contiguous int32 [K]");
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(q_weight.device());
+  check(slm_w4_prepack_weights(SLM_W4_GPTQ, q_weight.const_data_ptr<int32_t>(),
+                               has_perm ? perm.const_data_ptr<int32_t>() : nullptr, K, N,
+                               out.mutable_data_ptr(), current_stream(q_weight)),
+        "slm_w4_prepack_weights");
+}
+
+void awq_repack(const torch::Tensor& q_weight, torch::Tensor& out, int64_t num_bits) {
+  const int64_t K = q_weight.size(0), N = q_weight.size(1) * 8;
+  check_repack_args(q_weight, out, num_bits, K, N);
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(q_weight.device());
+  check(slm_w4_prepack_weights(SLM_W4_AWQ, q_weight.const_data_ptr<int32_t>(), nullptr, K, N,
+                               out.mutable_data_ptr(), current_stream(q_weight)),
+        "slm_w4_prepack_weights");
+}
+
+void gptq_gemm(const torch::Tensor& A, const torch::Tensor& B, torch::Tensor& C,
+               const torch::Tensor& scales, const torch::Tensor& zeros, const torch::Tensor& /*g_idx*/,
+               const torch::Tensor& perm, torch::Tensor& /*workspace*/, int num_bits, bool /*is_k_full*/,
+               bool has_zp, bool /*use_fp32_reduce*/) {
+  TORCH_CHECK(num_bits == 4, "only 4-bit weights are supported on the HIP int4 path, got ", num_bits);
+  TORCH_CHECK(A.dim() == 2 && C.dim() == 2 && A.stride(1) == 1 && C.stride(1) == 1);
+  const int64_t M = A.size(0), K = A.size(1), N = C.size(1);
+  TORCH_CHECK(C.size(0) == M && B.numel() == K * N / 8 && B.scalar_type() == torch::kInt && B.is_contiguous(),
+              "B must be the int32 [K/16, N*16/8] tensor gptq_repack / awq_repack produced");
+  TORCH_CHECK(scales.dim() == 2 && scales.size(1) == N && scales.is_contiguous() &&
+              scales.scalar_type() == A.scalar_type() && K % scales.size(0) == 0,
+              "scales must be [n_groups, N] of the activation dtype, plain column order");
+  const int64_t G = scales.size(0), gs = K / G;
+  const bool zp = has_zp && zeros.defined() && zeros.numel() > 0;
+  if (zp)
+    TORCH_CHECK(zeros.scalar_type() == torch::kInt && zeros.is_contiguous() && zeros.numel() == G * N / 8,
+                "zeros must be the AWQ checkpoint tensor [n_groups, N/8] int32");
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(A.device());
+  torch::Tensor sz;
+  {
+    const SzKey key{scales.const_data_ptr(), zp ? zeros.const_data_ptr() : nullptr,
+                    static_cast<int64_t>(scales._version()) * 65537 + (zp ? static_cast<int64_t>(zeros._version()) : 0),
+                    K, N};
+    std::lock_guard<std::mutex> lk(g_sz_mu);
+    auto it = g_sz_cache.find(key);
+    if (it != g_sz_cache.end() &&
+        !(same_live_storage(it->second.scales_st, scales) && (!zp || same_live_storage(it->second.zeros_st, zeros)))) {
+      g_sz_cache.erase(it);  // the address was recycled for another tensor
+      it = g_sz_cache.end();
+    }
+    if (it == g_sz_cache.end()) {
+      sz = torch::empty({G * N}, torch::dtype(torch::kInt).device(A.device()));
+      check(slm_w4_prepack_sz(zp ? SLM_W4_AWQ : SLM_W4_GPTQ, zp ? zeros.const_data_ptr<int32_t>() : nullptr,
+                              scales.const_data_ptr(), K, N, gs, dtype_code(scales), sz.mutable_data_ptr(),
+                              current_stream(A)),
+            "slm_w4_prepack_sz");
+      using WeakStorage = c10::weak_intrusive_ptr<c10::StorageImpl>;
+      const auto& keep_alive_of_zeros = zp ? zeros : scales;
+      g_sz_cache.emplace(key, SzEntry{sz, WeakStorage(scales.storage().getWeakStorageImpl()),
+                                      WeakStorage(keep_alive_of_zeros.storage().getWeakStorageImpl())});
+    } else {
+      sz = it->second.sz;
+    }
+  }
+  const bool has_perm = perm.defined() && perm.numel() > 0;
+  slm_w4_gemm_args g{};
+  g.a = A.const_data_ptr();
+  g.wq = B.const_data_ptr();
+  g.sz = sz.const_data_ptr();
+  g.perm = has_perm ? perm.const_data_ptr<int32_t>() : nullptr;
+  g.c = C.mutable_data_ptr();
+  g.M = M; g.K = K; g.N = N;
+  g.lda = A.stride(0); g.ldc = C.stride(0);
+  g.group_size = gs;
+  g.dtype = dtype_code(A);
+  if (M == 0) return;
+  const size_t need = slm_w4a16_gemm_workspace_bytes(&g);
+  torch::Tensor ws;
+  if (need > 0) {
+    ws = workspace_for(A, need);
+    g.workspace = ws.mutable_data_ptr();
+    g.workspace_bytes = ws.nbytes();
+  }
+  check(slm_w4a16_gemm(&g, current_stream(A)), "slm_w4a16_gemm");
+}
+
+}  // namespace marlin
 
 namespace slm {
 

@@ -61,10 +61,49 @@ void apply_rotary_pos_emb_and_append(torch::Tensor& query, torch::Tensor& key,
 void rms_norm(torch::Tensor& out, torch::Tensor input, torch::Tensor weight, float epsilon);
 void rms_norm_residual(torch::Tensor& out, torch::Tensor& residual, torch::Tensor input,
                        torch::Tensor weight, float epsilon);
+// src/kernels/activation_kernels.h:14: act(x) * y with x = input[..., :d], y = input[..., d:]
+torch::Tensor silu_with_mul(torch::Tensor input);
+// the same into a caller-owned buffer (graph-captured steps reuse static buffers)
 void silu_and_mul(torch::Tensor& out, torch::Tensor input);
 
 }  // namespace kernel
 }  // namespace llm
+
+// The reference's int4 kernel-level boundary, src/kernels/quantization/marlin.h:17-37 -- the
+// signatures verbatim, so scalellm/csrc/kernels.cu:24-54 (`_C.kernels.marlin_gemm`, `..._repack`)
+// and qlinear_{awq,gptq}_marlin_impl.cpp bind against this library unchanged.  What differs is
+// what the opaque tensors CARRY (the Marlin byte layout is an NVIDIA mma.m16n8k16 artefact):
+//   B / out  : same shape and dtype as Marlin's ([K/16, N*16/8] int32 = K*N/8 words), holding
+//              THIS library's MFMA-native layout (include/slm_hip.h section 3); only ever
+//              produced by gptq_repack / awq_repack and consumed by gptq_gemm;
+//   scales   : [G, N] T in plain column order -- drop the host-side marlin_permute_scales step
+//              (qlinear_awq_marlin_impl.cpp:34-60);
+//   zeros    : has_zp = true: [G, N/8] int32 exactly as the AWQ checkpoint stores them (drop
+//              marlin_awq_to_zero_points, :62-97); has_zp = false: ignored, zero = 8 (GPTQ sym);
+//   g_idx    : ignored (rows were sorted by group at repack time through `perm`);
+//   perm     : [K] int32 act-order permutation (empty = none): gptq_repack sorts the weight rows
+//              by it, gptq_gemm gathers the activation columns by it (gptq_gemm.cu:69-118);
+//   workspace: ignored (no locks: split-K partials live in the library's own scratch);
+//   num_bits : 4 only; is_k_full / use_fp32_reduce: accepted, the reduction is always fp32.
+namespace marlin {
+
+void gptq_gemm(const torch::Tensor& A,  // (m, k)
+               const torch::Tensor& B,  // (k/16, n*16/8): this library's layout
+               torch::Tensor& C,        // (m, n)
+               const torch::Tensor& scales, const torch::Tensor& zeros, const torch::Tensor& g_idx,
+               const torch::Tensor& perm, torch::Tensor& workspace, int num_bits, bool is_k_full,
+               bool has_zp, bool use_fp32_reduce);
+
+void gptq_repack(const torch::Tensor& q_weight,  // (k/8, n)
+                 const torch::Tensor& perm,      // (k) or empty
+                 torch::Tensor& out,             // (k/16, n*16/8)
+                 int64_t num_bits);
+
+void awq_repack(const torch::Tensor& q_weight,  // (k, n/8)
+                torch::Tensor& out,             // (k/16, n*16/8)
+                int64_t num_bits);
+
+}  // namespace marlin
 
 namespace slm {
 

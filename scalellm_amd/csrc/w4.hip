@@ -78,12 +78,14 @@ __global__ void __launch_bounds__(256) w4_prepack_sz_kernel(
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= G * N) return;
   const int64_t g = idx / N, n = idx % N;
-  const uint32_t zw = qzeros[g * (N / 8) + n / 8];
-  uint32_t z;
-  if (format == SLM_W4_GPTQ)
-    z = ((zw >> (4 * (n % 8))) & 0xFu) + 1u;  // qlinear_impl.cpp:45 (zeros.add_(1))
-  else
-    z = (zw >> (4 * awq_pos((int)(n % 8)))) & 0xFu;
+  uint32_t z = 8u;  // no zero-point tensor: symmetric quantisation, zero = 2^(bits-1) (Marlin has_zp = false)
+  if (qzeros) {
+    const uint32_t zw = qzeros[g * (N / 8) + n / 8];
+    if (format == SLM_W4_GPTQ)
+      z = ((zw >> (4 * (n % 8))) & 0xFu) + 1u;  // qlinear_impl.cpp:45 (zeros.add_(1))
+    else
+      z = (zw >> (4 * awq_pos((int)(n % 8)))) & 0xFu;
+  }
   const uint32_t zm = (dtype == SLM_BF16 ? 0x4300u : 0x6400u) + z;  // 128 + z  /  1024 + z
   sz[idx] = (uint32_t)scales[idx] | (zm << 16);
 }
@@ -582,29 +584,48 @@ SLM_API size_t slm_w4_packed_sz_bytes(int64_t K, int64_t N, int64_t group_size) 
   return (size_t)(K / group_size) * N * sizeof(uint32_t);
 }
 
-SLM_API int slm_w4_prepack(int32_t format, const int32_t* qweight, const int32_t* qzeros,
-                           const void* scales, const int32_t* perm, int64_t K, int64_t N,
-                           int64_t group_size, int32_t dtype, void* wq_out, void* sz_out,
-                           void* stream) {
-  if (!qweight || !qzeros || !scales || !wq_out || !sz_out) return SLM_ERR_INVALID_ARG;
+SLM_API int slm_w4_prepack_weights(int32_t format, const int32_t* qweight, const int32_t* perm,
+                                   int64_t K, int64_t N, void* wq_out, void* stream) {
+  if (!qweight || !wq_out) return SLM_ERR_INVALID_ARG;
   if (format != SLM_W4_GPTQ && format != SLM_W4_AWQ) return SLM_ERR_UNSUPPORTED;
-  if (dtype != SLM_F16 && dtype != SLM_BF16) return SLM_ERR_UNSUPPORTED;
-  if (K <= 0 || N <= 0 || K % 64 || N % 32 || group_size <= 0 || K % group_size)
-    return SLM_ERR_UNSUPPORTED;
+  if (K <= 0 || N <= 0 || K % 64 || N % 32) return SLM_ERR_UNSUPPORTED;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hip_clear_error();
   const int64_t words = K * N / 8;
   hipLaunchKernelGGL(w4_prepack_weight_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0,
                      st, format, reinterpret_cast<const uint32_t*>(qweight), perm, K, N,
                      reinterpret_cast<uint32_t*>(wq_out));
-  int rc = hip_check_launch();
-  if (rc != SLM_OK) return rc;
+  return hip_check_launch();
+}
+
+SLM_API int slm_w4_prepack_sz(int32_t format, const int32_t* qzeros, const void* scales, int64_t K,
+                              int64_t N, int64_t group_size, int32_t dtype, void* sz_out,
+                              void* stream) {
+  if (!scales || !sz_out) return SLM_ERR_INVALID_ARG;
+  if (format != SLM_W4_GPTQ && format != SLM_W4_AWQ) return SLM_ERR_UNSUPPORTED;
+  if (dtype != SLM_F16 && dtype != SLM_BF16) return SLM_ERR_UNSUPPORTED;
+  if (K <= 0 || N <= 0 || N % 32 || group_size <= 0 || K % group_size) return SLM_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hip_clear_error();
   const int64_t G = K / group_size;
   hipLaunchKernelGGL(w4_prepack_sz_kernel, dim3((unsigned)((G * N + 255) / 256)), dim3(256), 0, st,
                      format, reinterpret_cast<const uint32_t*>(qzeros),
                      reinterpret_cast<const uint16_t*>(scales), G, N, dtype,
                      reinterpret_cast<uint32_t*>(sz_out));
   return hip_check_launch();
+}
+
+SLM_API int slm_w4_prepack(int32_t format, const int32_t* qweight, const int32_t* qzeros,
+                           const void* scales, const int32_t* perm, int64_t K, int64_t N,
+                           int64_t group_size, int32_t dtype, void* wq_out, void* sz_out,
+                           void* stream) {
+  if (!qweight || !qzeros || !scales || !wq_out || !sz_out) return SLM_ERR_INVALID_ARG;
+  if (K <= 0 || N <= 0 || K % 64 || N % 32 || group_size <= 0 || K % group_size)
+    return SLM_ERR_UNSUPPORTED;
+  if (dtype != SLM_F16 && dtype != SLM_BF16) return SLM_ERR_UNSUPPORTED;
+  const int rc = slm_w4_prepack_weights(format, qweight, perm, K, N, wq_out, stream);
+  if (rc != SLM_OK) return rc;
+  return slm_w4_prepack_sz(format, qzeros, scales, K, N, group_size, dtype, sz_out, stream);
 }
 
 SLM_API int slm_w4_dequant(const void* wq, const void* sz, int64_t K, int64_t N,

@@ -266,7 +266,8 @@ class LlamaDecodeStep:
             nxt = self.layers[li + 1]["in_norm"] if li + 1 < len(self.layers) else self.final_norm
             reduce_add_norm(1, delta, nxt, L["down"].deferred if defer else None)
         last = (params.q_cu_seq_lens[1:] - 1).long()
-        logits = normed[last] @ self.lm_head  # plain library GEMM (hipBLASLt): not on the graded path
+        self.last_hidden = normed[last]  # final-norm output of each sequence's last token (tests)
+        logits = self.last_hidden @ self.lm_head  # plain library GEMM (hipBLASLt): not on the graded path
         if ar is not None and not return_logits and last.numel() <= ar.max_tokens \
                 and 4 * pa.world_size <= s.hidden:
             return self._greedy_over_vocab_shards(logits, ar)

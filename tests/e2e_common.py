@@ -100,6 +100,20 @@ class OracleLlama:
         self.inv_freq = np.ascontiguousarray(inv_freq, dtype=np.float32)
         self.kc = [np.zeros((n_slots, n_kv_heads, head_dim), np.float32) for _ in layers]
         self.vc = [np.zeros((n_slots, n_kv_heads, head_dim), np.float32) for _ in layers]
+        self._w_rounded = {}
+
+    def _w(self, li, name, n_tokens):
+        """Weight operand as the GPU GEMM sees it.  For M > 64 the int4 GEMM dequantises to T BEFORE
+        the MFMA ("PRE" form: (q - z) * s rounded to bf16 -- bit-faithful to the reference's Marlin
+        dequant, marlin/numeric_conversion.h:19-62,121-166); for M <= 64 the MFMA consumes the exact
+        integers and the scale is applied in fp32 ("POST" form), i.e. the exact fp32 weight."""
+        W = self.layers[li][name]
+        if self.storage is None or n_tokens <= 64:
+            return W
+        key = (li, name)
+        if key not in self._w_rounded:
+            self._w_rounded[key] = self._r(W)
+        return self._w_rounded[key]
 
     def _r(self, x):
         if self.storage is None:
@@ -122,7 +136,7 @@ class OracleLlama:
         normed = self._norm(resid, self.layers[0]["in_norm"])
         nq, nkv = H * D, HKV * D
         for li, W in enumerate(self.layers):
-            qkv = r(oracle.gemm_f32(normed, W["qkv"]))
+            qkv = r(oracle.gemm_f32(normed, self._w(li, "qkv", T)))
             q = r(oracle.rope(qkv[:, :nq].reshape(T, H, D), inp["positions"], self.inv_freq, D, False))
             k = r(oracle.rope(qkv[:, nq:nq + nkv].reshape(T, HKV, D), inp["positions"], self.inv_freq, D, False))
             v = np.ascontiguousarray(qkv[:, nq + nkv:].reshape(T, HKV, D))
@@ -131,13 +145,18 @@ class OracleLlama:
                                     inp["bcu"], self.B, D ** -0.5))
             # rms_norm_residual (normalization.h:42-52): h = x + residual in fp32, residual = T(h),
             # the norm reads the fp32 h
-            h = r(oracle.gemm_f32(a.reshape(T, -1), W["o"])) + resid
+            h = r(oracle.gemm_f32(a.reshape(T, -1), self._w(li, "o", T))) + resid
             resid = r(h)
+            resid_mid = h
             normed = self._norm(h, W["post_norm"])
-            act = r(oracle.silu_mul(r(oracle.gemm_f32(normed, W["gate_up"]))))
-            h = r(oracle.gemm_f32(act, W["down"])) + resid
+            act = r(oracle.silu_mul(r(oracle.gemm_f32(normed, self._w(li, "gate_up", T)))))
+            h = r(oracle.gemm_f32(act, self._w(li, "down", T))) + resid
             resid = r(h)
             nxt = self.layers[li + 1]["in_norm"] if li + 1 < len(self.layers) else self.final_norm
             normed = self._norm(h, nxt)
+            # last layer's intermediates, for stage-by-stage diagnosis against the GPU buffers
+            self.trace = dict(q=q, k=k, v=v, attn=a, post_normed=self._norm(resid_mid, W["post_norm"]),
+                              act=act, resid=resid, normed=normed)
         last = inp["q_cu"][1:] - 1
-        return r(oracle.gemm_f32(np.ascontiguousarray(normed[last]), self.lm_head))
+        self.last_hidden = np.ascontiguousarray(normed[last])
+        return r(oracle.gemm_f32(self.last_hidden, self.lm_head))

@@ -149,3 +149,97 @@ def test_shim_fused_allreduce_thread_per_rank(world, n_tokens, hidden):
     d_fused, d_sum, err = float(line[1]), float(line[2]), int(line[3])
     assert err == 0
     assert d_fused == 0.0 and d_sum == 0.0
+
+
+# ------------------------------------------------------------------------------------------------
+# the LAYER boundary in C++: slm::{Column,Row}ParallelQLinearHipImpl behind the reference's
+# factory functions (parallel_linear.cpp:103-165) and ParallelLinearImpl interface
+# (parallel_linear.h:17-37)
+# ------------------------------------------------------------------------------------------------
+def _ckpt(case):
+    d = {"qweight": torch.from_numpy(case["qweight"]), "qzeros": torch.from_numpy(case["qzeros"]),
+         "scales": torch.from_numpy(case["scales_bits"].view(np.int16)).view(torch.bfloat16)}
+    if case["g_idx"] is not None:
+        d["g_idx"] = torch.from_numpy(case["g_idx"])
+    return d
+
+
+def _oracle_dense(case):
+    if case["fmt"] == "awq":
+        return oracle.awq_dequant(case["qweight"], case["qzeros"], case["scales"], case["group_size"])
+    return oracle.gptq_dequant(case["qweight"], case["qzeros"], case["scales"], case["group_size"], case["g_idx"])
+
+
+@pytest.mark.parametrize("fmt", ["awq", "gptq"])
+def test_cpp_parallel_qlinear_impls_world1_and_tp2_sharding(shim, fmt):
+    """Column / row parallel int4 layers through the C++ factory: checkpoint tensors arrive on the
+    CPU (as the loader hands them over), every rank keeps its shard (column: dim 1, row: dim 0),
+    repacks lazily at the first forward.  world 1 == oracle; for world 2 the concatenated column
+    outputs and the summed row partials (+ bias once, after the sum) == the world-1 result."""
+    K, N, gs, M = 512, 256, 128, 24
+    case = helpers.make_quant_case(31, K, N, gs, fmt, "bf16")
+    sd = _ckpt(case)
+    bias = torch.randn(N, dtype=torch.bfloat16)
+    sd["bias"] = bias
+    args = (fmt, 4, gs, False, fmt == "gptq" and False, fmt == "awq")   # bits, group, desc_act, is_sym, zero_point
+    a = torch.randn(M, K, device=DEV, dtype=torch.bfloat16)
+    ref = oracle.gemm_f32(a.float().cpu().numpy(), _oracle_dense(case)) + bias.float().numpy()[None]
+    rel = lambda got: float(np.abs(got.float().cpu().numpy() - ref).mean() / np.abs(ref).mean())  # noqa: E731
+
+    col = shim.create_column_parallel_qlinear(K, N, True, False, *args, 0, 1, torch.bfloat16, 0)
+    with pytest.raises(RuntimeError, match="not loaded"):
+        col.verify_loaded_weights("layer.0.")
+    col.load_state_dict(sd)
+    col.verify_loaded_weights("layer.0.")
+    assert rel(col.forward(a)) < 8e-3
+    row = shim.create_row_parallel_qlinear(K, N, True, True, *args, 0, 1, torch.bfloat16, 0)
+    row.load_state_dict(sd)
+    assert rel(row.forward(a)) < 8e-3
+
+    cols = []
+    for r in range(2):   # column parallel, world 2: each rank N/2 columns (+ its half of the bias)
+        lin = shim.create_column_parallel_qlinear(K, N, True, False, *args, r, 2, torch.bfloat16, 0)
+        lin.load_state_dict(sd)
+        lin.verify_loaded_weights()
+        cols.append(lin.forward(a))
+    assert cols[0].shape == (M, N // 2) and rel(torch.cat(cols, dim=-1)) < 8e-3
+    sd_nb = {k: v for k, v in sd.items() if k != "bias"}
+    parts = []
+    for r in range(2):   # row parallel, world 2: each rank K/2 rows; no process group = partial sums
+        lin = shim.create_row_parallel_qlinear(K, N, False, False, *args, r, 2, torch.bfloat16, 0)
+        lin.load_state_dict(sd_nb)
+        parts.append(lin.forward(a).float())   # input NOT parallelised: the layer takes its K slice
+    assert rel((parts[0] + parts[1] + bias.to(DEV).float()).to(torch.bfloat16)) < 8e-3
+
+
+def test_cpp_parallel_qlinear_fused_load_and_argument_checks(shim):
+    """The fused (qkv / gate_up) load path: one checkpoint tensor set per prefix, arriving in any
+    order and possibly in different state-dict files, concatenated on dim 1; and the reference's
+    argument checks (check_awq_quant_args, shape divisibility)."""
+    K, gs, M = 256, 128, 8
+    cases = [helpers.make_quant_case(40 + i, K, n, gs, "awq", "bf16") for i, n in enumerate((128, 64, 64))]
+    prefixes = ["q_proj.", "k_proj.", "v_proj."]
+    lin = shim.create_column_parallel_qlinear(K, 256, False, False, "awq", 4, gs, False, False, True, 0, 1,
+                                              torch.bfloat16, 0)
+    file1 = {p + k: v for p, c in zip(prefixes[:2], cases[:2]) for k, v in _ckpt(c).items()}
+    file2 = {prefixes[2] + k: v for k, v in _ckpt(cases[2]).items()}
+    lin.load_state_dict_fused(file2, prefixes)            # v_proj first, from another file
+    with pytest.raises(RuntimeError, match="not loaded"):
+        lin.verify_loaded_weights()
+    lin.load_state_dict_fused(file1, prefixes)
+    lin.verify_loaded_weights()
+    a = torch.randn(M, K, device=DEV, dtype=torch.bfloat16)
+    got = lin.forward(a).float().cpu().numpy()
+    ref = np.concatenate([oracle.gemm_f32(a.float().cpu().numpy(), _oracle_dense(c)) for c in cases], axis=1)
+    assert np.abs(got - ref).mean() / np.abs(ref).mean() < 8e-3
+    mk = shim.create_column_parallel_qlinear
+    with pytest.raises(RuntimeError, match="Unsupported quant method"):
+        mk(K, 256, False, False, "squeezellm", 4, gs, False, False, True, 0, 1, torch.bfloat16, 0)
+    with pytest.raises(RuntimeError, match="zero_point"):
+        mk(K, 256, False, False, "awq", 4, gs, False, True, False, 0, 1, torch.bfloat16, 0)
+    with pytest.raises(RuntimeError, match="group_size"):
+        mk(K, 256, False, False, "awq", 4, 48, False, False, True, 0, 1, torch.bfloat16, 0)
+    with pytest.raises(RuntimeError, match="4-bit"):
+        mk(K, 256, False, False, "gptq", 8, gs, False, True, False, 0, 1, torch.bfloat16, 0)
+    with pytest.raises(RuntimeError, match="not divisible"):
+        mk(K, 250, False, False, "awq", 4, gs, False, False, True, 0, 4, torch.bfloat16, 0)
