@@ -29,8 +29,6 @@ enum TuneKey : int {
   TUNE_W4_SPLITK,         // SLM_W4_SPLITK         forced split-K
   TUNE_W4_POST,           // SLM_W4_POST
   TUNE_W4_FUSED_REDUCE,   // SLM_W4_FUSED_REDUCE   0 = separate split-K reduce launch
-  TUNE_W4_STREAM,         // SLM_W4_STREAM         0 = never use the barrier-free small-M stream kernel
-  TUNE_W4_STREAM_KW,      // SLM_W4_STREAM_KW      forced in-workgroup K split of the stream kernel
   TUNE_COUNT
 };
 

@@ -484,6 +484,7 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   int ntw = tune_get(TUNE_W4_NTW, 1);
   if (ntw != 1 && ntw != 2) ntw = 1;
   if (mt >= 4) ntw = 1;
+  if (pl->small) ntw = 1;
   pl->mt = mt;
   pl->ntw = ntw;
   const int bm = mt == 16 ? 256 : 32 * mt, bn = mt == 16 ? 256 : 128 * ntw;
