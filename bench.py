@@ -96,6 +96,48 @@ def measure_attention_kernel(model, tokens, positions, params, n_launch):
     return sum(times) / len(times), times[len(times) // 2]
 
 
+def measure_attention_traffic_live(bs, kv_len, n_heads, n_kv_heads, block):
+    """HBM bytes per paged-attention launch from the L2's memory-side counters, as
+    MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE
+    `rocprofv3 --pmc` passes (kernel-trace / stats only alongside), FETCH_SIZE x 2 on gfx950 (it
+    tallies 64 B per 128-B request of a wide coalesced stream), WRITE_SIZE as reported; both are
+    in KiB.  The profiled child (tools/profile_attn.py) launches the same kernel on the same
+    shapes, 4 times; the per-launch mean is returned."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    tool = os.path.join(ROOT, "tools", "profile_attn.py")
+    env = dict(os.environ, SKIP_GEMM="1", N_LAUNCH="4", BS=str(bs), SEQLEN=str(kv_len), BLOCK=str(block),
+               HEADS=f"{n_heads},{n_kv_heads}", TMPDIR="/tmp")
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="slm_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                                sys.executable, tool], cwd="/tmp", env=env, capture_output=True, text=True,
+                               timeout=300)
+            per = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if "attn_token_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            per.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not per:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})"
+            vals[counter] = sum(per) / len(per)
+        except Exception as e:  # noqa: BLE001 -- the roofline line does not depend on the profiler
+            return None, f"rocprofv3 --pmc {counter}: {type(e).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    traffic = int(vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024)
+    return traffic, ("live: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE passes of this run (4 launches each), "
+                     "FETCH_SIZE x 2 (gfx950 correction), KiB -> bytes")
+
+
 def measure_gemm(model, T):
     """int4 GEMM TFLOP/s of the largest layer GEMM (gate_up) at M = batch tokens (hipGraph of 20
     launches between HIP events)."""
@@ -320,6 +362,8 @@ def main():
                     "gptq with symmetric zero points (70b)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child "
+                    "passes that measure roofline.traffic live (~20 s)")
     ap.add_argument("--kv-fill", default="randn", choices=["tile", "randn", "consistent"],
                     help="consistent: every rank draws the full-head history and keeps its shard, so "
                     "TP=N and TP=1 decode the same model state (tests compare their tokens)")
@@ -457,22 +501,18 @@ def main():
     avg_us, med_us = measure_attention_kernel(model, tokens, positions, params, n_launch=32)
     nbytes = attn_algo_bytes(bs, L, model.n_heads, model.n_kv_heads, shape.head_dim, B)
     achieved = nbytes / avg_us / 1e3  # GB/s
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "attn_pmc.json")
-    if os.path.exists(pmc):
-        try:
-            with open(pmc) as f:
-                rec = json.load(f)
-            if rec.get("bs") == bs and rec.get("seqlen") == L and rec.get("n_gpus", 1) == world:
-                traffic = rec.get("hbm_bytes_per_launch")
-        except Exception:  # noqa: BLE001
-            traffic = None
+    # HBM traffic of that launch from the PMC counters, measured IN THIS RUN (rank 0, N = 1): two
+    # rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) over a child process
+    # that launches the same kernel on the same shapes; null when rocprofv3 is unavailable
+    gemm = measure_gemm(model, bs)  # (before the profiler children below: same clocks as the timed steps)
+    traffic, traffic_src = (None, None)
+    if rank == 0 and world == 1 and not args.no_traffic:
+        traffic, traffic_src = measure_attention_traffic_live(bs, L, model.n_heads, model.n_kv_heads, B)
     roofline = dict(kernel="attn_token_kernel (paged-attention decode)", bound="hbm",
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic,
+                    frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=nbytes, avg_launch_us=round(avg_us, 2),
                     median_launch_us=round(med_us, 2), launches="5 x 32 (hipGraph replay)")
-    gemm = measure_gemm(model, bs)
 
     out = None
     if rank == 0:

@@ -24,7 +24,7 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ["--layers", "2", "--bs", "8", "--seqlen", "256", "--steps", "2", "--warmup", "1",
-          "--no-cpu-baseline", "--kv-fill", "consistent"]
+          "--no-cpu-baseline", "--no-traffic", "--kv-fill", "consistent"]
 
 
 def _free_port():
@@ -80,7 +80,7 @@ def test_bench_70b_config_reduced_layers_runs_on_one_gpu():
     """BASELINE configs[3] plumbing (Llama-3-70B shapes, GPTQ symmetric g128, bs=128) with the layer
     count cut to 2 so it fits a test: shapes, symmetric zero points, JSON labelling."""
     rec, _ = _run([sys.executable, "bench.py", "--gpus", "1", "--model", "70b", "--layers", "2",
-                   "--seqlen", "512", "--steps", "2", "--warmup", "1"], {})
+                   "--seqlen", "512", "--steps", "2", "--warmup", "1", "--no-traffic"], {})
     assert rec["config"]["model"] == "70b" and rec["config"]["global_batch"] == 128
     assert "gptq (symmetric)" in rec["config"]["workload"] and rec["config"]["reduced_model"] is True
     assert rec["int4_gemm"]["shape"] == [128, 8192, 57344]

@@ -19,7 +19,8 @@ def main():
     n = int(os.environ.get("N_LAUNCH", "10"))
     bs = int(os.environ.get("BS", "256"))
     dev = torch.device("cuda", 0)
-    H, HKV, D, B, L = 32, 8, 128, 16, 4096
+    H, HKV = (int(x) for x in os.environ.get("HEADS", "32,8").split(","))
+    D, B, L = 128, int(os.environ.get("BLOCK", "16")), int(os.environ.get("SEQLEN", "4096"))
     tokens, positions, p, n_blocks = make_decode_inputs(bs, L, B, dev, seed=1)
     g = torch.Generator(device=dev).manual_seed(0)
     q = torch.randn(bs, H, D, device=dev, dtype=torch.bfloat16, generator=g)
