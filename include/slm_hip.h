@@ -159,6 +159,15 @@ SLM_API int slm_set_kv_cache(const int32_t* slot_ids,  /* [n_tokens]           *
 /*      perm[K] int32 (act-order only): row k' of wq = checkpoint row perm[k']*/
 /* ========================================================================== */
 typedef enum slm_w4_format { SLM_W4_GPTQ = 0, SLM_W4_AWQ = 1 } slm_w4_format;
+#define SLM_W4_FORMAT_MASK 0xF
+/* OR into `format`: the checkpoint tensors are a merged [gate | up] column-parallel weight (the
+ * reference builds it by concatenating gate_proj and up_proj along N,
+ * layers/linear/multi_parallel_linear.cpp:14-41; N = 2 * intermediate, N % 64 == 0).  The packed
+ * form then interleaves the two halves by 32-column tile -- packed tile 2j = columns
+ * [32j, 32j+32) of gate, packed tile 2j+1 = the same columns of up -- which is what lets
+ * slm_w4a16_gemm apply SiLU*mul in its epilogue (SLM_W4_SILU_MUL).  Without that flag a GEMM on
+ * paired weights returns the columns in the packed (interleaved) order. */
+#define SLM_W4_PAIRED 0x10
 
 SLM_API size_t slm_w4_packed_weight_bytes(int64_t K, int64_t N);
 SLM_API size_t slm_w4_packed_sz_bytes(int64_t K, int64_t N, int64_t group_size);
@@ -213,6 +222,13 @@ typedef struct slm_w4_gemm_args {
  * row-parallel linear.  Ignored (normal reduce) when bias != NULL.  Whether a given call defers is
  * a pure function of the argument block: ask slm_w4a16_gemm_deferred_splits first. */
 #define SLM_W4_DEFER_REDUCE 1
+/* flags: wq / sz were packed with SLM_W4_PAIRED and c is [M, N/2] (ldc >= N/2):
+ *   c[m, i] = T( silu(g) * u ),  g = T(acc[m, gate col i] + bias), u = T(acc[m, up col i] + bias)
+ * -- bit-identical to the unfused sequence "GEMM into [M, N], then slm_silu_mul"
+ * (kernel::act_and_mul, src/kernels/activation_kernels.cu:84, after the merged gate_up linear of
+ * the MLP), minus one launch and the round trip of the [M, N] intermediate.  bias, if given, is in
+ * packed column order.  Needs N % 64 == 0; cannot be combined with SLM_W4_DEFER_REDUCE. */
+#define SLM_W4_SILU_MUL 2
 
 SLM_API size_t slm_w4a16_gemm_workspace_bytes(const slm_w4_gemm_args* a);
 /* number of partial slabs the call will leave in the workspace (>= 2), or 0 when it writes c as usual */

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libslm_hip.so")
 
 SLM_F16, SLM_BF16 = 0, 1
 SLM_W4_GPTQ, SLM_W4_AWQ = 0, 1
+SLM_W4_PAIRED = 0x10
 
 
 class SlmError(RuntimeError):
@@ -51,6 +52,7 @@ class W4GemmArgs(C.Structure):
 
 
 SLM_W4_DEFER_REDUCE = 1
+SLM_W4_SILU_MUL = 2
 
 
 class ArArgs(C.Structure):

@@ -13,9 +13,9 @@ namespace {
 const char* const kTuneNames[TUNE_COUNT] = {
     "SLM_ATTN_NW",          "SLM_ATTN_SPLITS",      "SLM_ATTN_HGW",     "SLM_ATTN_TILE",
     "SLM_ATTN_TILE_SPLITS", "SLM_ATTN_TILE_PF",     "SLM_ATTN_U",       "SLM_ATTN_NT",
-    "SLM_ATTN_FUSED_COMBINE", "SLM_W4_GEMV",        "SLM_W4_GEMV_REFILL", "SLM_W4_SMALL",
+    "SLM_W4_GEMV",          "SLM_W4_GEMV_REFILL",   "SLM_W4_GEMV_KS",   "SLM_W4_SMALL",
     "SLM_W4_MT",            "SLM_W4_NTW",           "SLM_W4_PC",        "SLM_W4_SPLITK",
-    "SLM_W4_POST",          "SLM_W4_FUSED_REDUCE",
+    "SLM_W4_POST",
 };
 std::atomic<int32_t> g_tune[TUNE_COUNT];
 std::once_flag g_tune_once;

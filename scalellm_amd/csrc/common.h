@@ -124,9 +124,28 @@ __device__ __forceinline__ void group_sum_many(float* v) {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// 8 x (silu(gate) * up) in fp32, rounded RN to T: THE formula of the SiLU*mul glue kernel
-// (kernel::act_and_mul, reference src/kernels/activation_kernels.cu:84), shared with the GEMM
-// prologues that fuse it so that both paths give identical bits
+// silu(gate) * up in fp32 on values that are already exact in T: THE formula of the SiLU*mul glue
+// kernel (kernel::act_and_mul, reference src/kernels/activation_kernels.cu:84), shared with the
+// GEMM epilogues that fuse it so that both paths give identical bits
+__device__ __forceinline__ float silu_mul1(const float g, const float u) {
+  const float sig = __builtin_amdgcn_rcpf(1.0f + fast_exp2(-g * 1.4426950408889634f));
+  float r = g * sig * u;
+  // the product is an fp32 value in a register before any conversion to T: without this the
+  // compiler may fold "multiply, then round to fp16" into one v_fma_mixlo_f16 (single rounding) in
+  // some callers and not in others (v_pk_mul_f32 + v_cvt), and the fused / unfused paths would
+  // differ in the last bit on ties
+  asm("" : "+v"(r));
+  return r;
+}
+
+// the fused-epilogue form: fp32 accumulators -> rounded to T (what the unfused GEMM would have
+// stored) -> silu_mul1
+template <typename T>
+__device__ __forceinline__ float silu_mul_acc(const float gate_acc, const float up_acc) {
+  return silu_mul1(lo_f32<T>((uint32_t)pack1<T>(gate_acc)), lo_f32<T>((uint32_t)pack1<T>(up_acc)));
+}
+
+// 8 x silu_mul1, rounded RN to T
 template <typename T>
 __device__ __forceinline__ u32x4 silu_mul8(const u32x4 g, const u32x4 u) {
   const float gf[8] = {lo_f32<T>(g.x), hi_f32<T>(g.x), lo_f32<T>(g.y), hi_f32<T>(g.y),
@@ -135,10 +154,7 @@ __device__ __forceinline__ u32x4 silu_mul8(const u32x4 g, const u32x4 u) {
                        lo_f32<T>(u.z), hi_f32<T>(u.z), lo_f32<T>(u.w), hi_f32<T>(u.w)};
   float o[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float sig = __builtin_amdgcn_rcpf(1.0f + fast_exp2(-gf[j] * 1.4426950408889634f));
-    o[j] = gf[j] * sig * uf[j];
-  }
+  for (int j = 0; j < 8; ++j) o[j] = silu_mul1(gf[j], uf[j]);
   u32x4 r;
   r.x = pack2<T>(o[0], o[1]); r.y = pack2<T>(o[2], o[3]);
   r.z = pack2<T>(o[4], o[5]); r.w = pack2<T>(o[6], o[7]);

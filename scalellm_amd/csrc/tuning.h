@@ -19,16 +19,15 @@ enum TuneKey : int {
   TUNE_ATTN_TILE_PF,      // SLM_ATTN_TILE_PF      tile kernel prefetch variant
   TUNE_ATTN_U,            // SLM_ATTN_U            K/V register ring depth (2/4)
   TUNE_ATTN_NT,           // SLM_ATTN_NT           non-temporal KV loads on/off
-  TUNE_ATTN_FUSED_COMBINE,  // SLM_ATTN_FUSED_COMBINE  0 = separate combine launch
   TUNE_W4_GEMV,           // SLM_W4_GEMV           0 off, 1 = M == 1 only, 2 = M <= 4
   TUNE_W4_GEMV_REFILL,    // SLM_W4_GEMV_REFILL
+  TUNE_W4_GEMV_KS,        // SLM_W4_GEMV_KS        forced K slices per GEMV workgroup (1/2/4/8)
   TUNE_W4_SMALL,          // SLM_W4_SMALL          0 = never use the small-M kernel
   TUNE_W4_MT,             // SLM_W4_MT             forced M tile (1/2/4/8/16)
   TUNE_W4_NTW,            // SLM_W4_NTW
   TUNE_W4_PC,             // SLM_W4_PC
   TUNE_W4_SPLITK,         // SLM_W4_SPLITK         forced split-K
   TUNE_W4_POST,           // SLM_W4_POST
-  TUNE_W4_FUSED_REDUCE,   // SLM_W4_FUSED_REDUCE   0 = separate split-K reduce launch
   TUNE_COUNT
 };
 

@@ -43,6 +43,16 @@ __device__ __forceinline__ int awq_pos(int col_in_word) {  // [0,2,4,6,1,3,5,7] 
   return (col_in_word >> 1) + 4 * (col_in_word & 1);
 }
 
+// SLM_W4_PAIRED: the checkpoint tensor is a merged [gate | up] column-parallel weight
+// (layers/linear/multi_parallel_linear.cpp:14-41 concatenates the two along N); its packed form
+// interleaves the halves by 32-column tile -- packed tile 2j = gate tile j, packed tile 2j+1 = up
+// tile j -- so the wave (pair) that owns gate columns also owns the matching up columns and can
+// apply SiLU*mul in the GEMM epilogue (SLM_W4_SILU_MUL).
+__device__ __forceinline__ int64_t paired_src_col(int format, int64_t n_packed, int64_t N) {
+  if (!(format & SLM_W4_PAIRED)) return n_packed;
+  return (n_packed >> 6) * 32 + (n_packed & 31) + ((n_packed & 32) ? N / 2 : 0);
+}
+
 // ------------------------------------------------------------------------------------------
 // prepack: checkpoint formats -> wq / sz   (bit-exact integer work)
 // ------------------------------------------------------------------------------------------
@@ -55,14 +65,14 @@ __global__ void __launch_bounds__(256) w4_prepack_weight_kernel(
   const int lane = (int)((widx >> 2) & 63);
   const int64_t tile = widx >> 8;
   const int64_t nt = tile % (N / 32), kt = tile / (N / 32);  // kt-major: see layout note
-  const int64_t n = nt * 32 + (lane & 31);
+  const int64_t n = paired_src_col(format, nt * 32 + (lane & 31), N);
   const int64_t kb = kt * 64 + j * 16 + (lane >> 5) * 8;
   uint32_t out = 0;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int64_t k = perm ? (int64_t)perm[kb + e] : kb + e;
     uint32_t q;
-    if (format == SLM_W4_GPTQ)
+    if ((format & SLM_W4_FORMAT_MASK) == SLM_W4_GPTQ)
       q = (qweight[(k / 8) * N + n] >> (4 * (k % 8))) & 0xFu;
     else
       q = (qweight[k * (N / 8) + n / 8] >> (4 * awq_pos((int)(n % 8)))) & 0xFu;
@@ -77,17 +87,17 @@ __global__ void __launch_bounds__(256) w4_prepack_sz_kernel(
     int64_t N, int dtype, uint32_t* __restrict__ sz) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= G * N) return;
-  const int64_t g = idx / N, n = idx % N;
+  const int64_t g = idx / N, n = paired_src_col(format, idx % N, N);
   uint32_t z = 8u;  // no zero-point tensor: symmetric quantisation, zero = 2^(bits-1) (Marlin has_zp = false)
   if (qzeros) {
     const uint32_t zw = qzeros[g * (N / 8) + n / 8];
-    if (format == SLM_W4_GPTQ)
+    if ((format & SLM_W4_FORMAT_MASK) == SLM_W4_GPTQ)
       z = ((zw >> (4 * (n % 8))) & 0xFu) + 1u;  // qlinear_impl.cpp:45 (zeros.add_(1))
     else
       z = (zw >> (4 * awq_pos((int)(n % 8)))) & 0xFu;
   }
   const uint32_t zm = (dtype == SLM_BF16 ? 0x4300u : 0x6400u) + z;  // 128 + z  /  1024 + z
-  sz[idx] = (uint32_t)scales[idx] | (zm << 16);
+  sz[idx] = (uint32_t)scales[g * N + n] | (zm << 16);
 }
 
 // debug / parity: dense W[K, N] in T from the packed form (uses W4Dq = the GEMM's dequant)
@@ -379,6 +389,42 @@ __global__ void __launch_bounds__(256, (POST && PC * MT == 4 && MT < 4) ? 1 : 2)
   }
 
   // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (p.silu && p.split_k == 1) {
+    // SLM_W4_SILU_MUL: column tiles are (gate, up) pairs.  NTW == 2: both tiles of a pair are this
+    // wave's own; NTW == 1: waves (0, 1) and (2, 3) hold a pair -- the up wave hands its T-rounded
+    // tile to the gate wave through the (now idle) A buffers, same lane, same (m, r).
+    const uint16_t* bias = reinterpret_cast<const uint16_t*>(p.bias);
+    uint16_t* ex = reinterpret_cast<uint16_t*>(smem) + (wave >> 1) * (MT * 1024);
+    if constexpr (NTW == 1) {
+      if (wave & 1) {
+        const float bu = bias ? lo_f32<T>((uint32_t)bias[ntile[0] * 32 + (lane & 31)]) : 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ex[(m * 16 + r) * 64 + lane] = pack1<T>(acc[0][m][r] + bu);
+      }
+      __syncthreads();
+      if (wave & 1) return;
+    }
+    if (!nvalid[0]) return;
+    const int64_t gcol = ntile[0] * 32 + (lane & 31), ocol = (ntile[0] >> 1) * 32 + (lane & 31);
+    const float bg = bias ? lo_f32<T>((uint32_t)bias[gcol]) : 0.f;
+    const float bu2 = (NTW == 2 && bias) ? lo_f32<T>((uint32_t)bias[gcol + 32]) : 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float g = lo_f32<T>((uint32_t)pack1<T>(acc[0][m][r] + bg));
+        float u;
+        if constexpr (NTW == 2) u = lo_f32<T>((uint32_t)pack1<T>(acc[NTW - 1][m][r] + bu2));
+        else u = lo_f32<T>((uint32_t)ex[(m * 16 + r) * 64 + lane]);
+        if (row < p.M)
+          reinterpret_cast<uint16_t*>(p.c)[row * p.ldc + ocol] = pack1<T>(silu_mul1(g, u));
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < NTW; ++t) {
     if (!nvalid[t]) continue;
@@ -425,6 +471,32 @@ __global__ void __launch_bounds__(256) w4_splitk_reduce_kernel(const float* __re
   *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(c) + m * ldc + n) = r;
 }
 
+// SLM_W4_SILU_MUL with split-K: C[m, i] = T( silu(g) * u ), g / u = T( sum_s part[s][m][col] + bias )
+// at the gate / up columns of output column i (packed tile pair 2j, 2j+1; N = packed width)
+template <typename T>
+__global__ void __launch_bounds__(256) w4_splitk_reduce_silu_kernel(
+    const float* __restrict__ part, const void* __restrict__ bias, void* __restrict__ c, int64_t M,
+    int64_t N, int64_t ldc, int split_k) {
+  const int64_t idx4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // 4 output columns per thread
+  const int64_t half = N / 2;
+  if (idx4 * 4 >= M * half) return;
+  const int64_t m = (idx4 * 4) / half, oc = (idx4 * 4) % half;
+  const int64_t gc = (oc >> 5) * 64 + (oc & 31);
+  f32x4 g = splitk_sum4(part + m * N + gc, M * N, split_k);
+  f32x4 u = splitk_sum4(part + m * N + gc + 32, M * N, split_k);
+  if (bias) {
+    const uint16_t* bp = reinterpret_cast<const uint16_t*>(bias) + gc;
+    const u32x2 bg = *reinterpret_cast<const u32x2*>(bp);
+    const u32x2 bu = *reinterpret_cast<const u32x2*>(bp + 32);
+    g.x += lo_f32<T>(bg.x); g.y += hi_f32<T>(bg.x); g.z += lo_f32<T>(bg.y); g.w += hi_f32<T>(bg.y);
+    u.x += lo_f32<T>(bu.x); u.y += hi_f32<T>(bu.x); u.z += lo_f32<T>(bu.y); u.w += hi_f32<T>(bu.y);
+  }
+  u32x2 r;
+  r.x = pack2<T>(silu_mul_acc<T>(g.x, u.x), silu_mul_acc<T>(g.y, u.y));
+  r.y = pack2<T>(silu_mul_acc<T>(g.z, u.z), silu_mul_acc<T>(g.w, u.w));
+  *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(c) + m * ldc + oc) = r;
+}
+
 // ------------------------------- host side ------------------------------------------
 struct GemmPlan {
   int mt, ntw, ng, pc, post, small, gemv, split_k, chunks_per_split, n_mblocks, n_nblocks;
@@ -436,6 +508,11 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   if (a->M < 0 || a->K <= 0 || a->N <= 0) return SLM_ERR_INVALID_ARG;
   if (a->dtype != SLM_F16 && a->dtype != SLM_BF16) return SLM_ERR_UNSUPPORTED;
   if (a->K % W4_KC || a->N % 32) return SLM_ERR_UNSUPPORTED;  // reference: K%128, N%64
+  if (a->flags & ~(SLM_W4_DEFER_REDUCE | SLM_W4_SILU_MUL)) return SLM_ERR_INVALID_ARG;
+  if (a->flags & SLM_W4_SILU_MUL) {
+    if (a->flags & SLM_W4_DEFER_REDUCE) return SLM_ERR_INVALID_ARG;
+    if (a->N % 64) return SLM_ERR_UNSUPPORTED;
+  }
   const int64_t gs = a->group_size;
   if (!(gs == 32 || gs == 64 || (gs >= 128 && gs % 128 == 0 && is_pow2(gs)) || gs == a->K))
     return SLM_ERR_UNSUPPORTED;
@@ -573,6 +650,13 @@ static void launch_gemm(const GemmKParams& kp, const GemmPlan& pl, hipStream_t s
 
 using namespace slm;
 
+static bool w4_format_ok(int32_t format, int64_t N) {
+  const int32_t base = format & SLM_W4_FORMAT_MASK;
+  if (format & ~(SLM_W4_FORMAT_MASK | SLM_W4_PAIRED)) return false;
+  if (base != SLM_W4_GPTQ && base != SLM_W4_AWQ) return false;
+  return !(format & SLM_W4_PAIRED) || N % 64 == 0;
+}
+
 extern "C" {
 
 SLM_API size_t slm_w4_packed_weight_bytes(int64_t K, int64_t N) {
@@ -588,7 +672,7 @@ SLM_API size_t slm_w4_packed_sz_bytes(int64_t K, int64_t N, int64_t group_size) 
 SLM_API int slm_w4_prepack_weights(int32_t format, const int32_t* qweight, const int32_t* perm,
                                    int64_t K, int64_t N, void* wq_out, void* stream) {
   if (!qweight || !wq_out) return SLM_ERR_INVALID_ARG;
-  if (format != SLM_W4_GPTQ && format != SLM_W4_AWQ) return SLM_ERR_UNSUPPORTED;
+  if (!w4_format_ok(format, N)) return SLM_ERR_UNSUPPORTED;
   if (K <= 0 || N <= 0 || K % 64 || N % 32) return SLM_ERR_UNSUPPORTED;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hip_clear_error();
@@ -603,7 +687,7 @@ SLM_API int slm_w4_prepack_sz(int32_t format, const int32_t* qzeros, const void*
                               int64_t N, int64_t group_size, int32_t dtype, void* sz_out,
                               void* stream) {
   if (!scales || !sz_out) return SLM_ERR_INVALID_ARG;
-  if (format != SLM_W4_GPTQ && format != SLM_W4_AWQ) return SLM_ERR_UNSUPPORTED;
+  if (!w4_format_ok(format, N)) return SLM_ERR_UNSUPPORTED;
   if (dtype != SLM_F16 && dtype != SLM_BF16) return SLM_ERR_UNSUPPORTED;
   if (K <= 0 || N <= 0 || N % 32 || group_size <= 0 || K % group_size) return SLM_ERR_UNSUPPORTED;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -667,7 +751,9 @@ SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream) {
   if (rc != SLM_OK) return rc;
   if (a->M == 0) return SLM_OK;
   if (!a->a || !a->wq || !a->sz || !a->c) return SLM_ERR_INVALID_ARG;
-  if (!aligned16(a->a) || !aligned16(a->wq) || a->lda % 8 || a->lda < a->K || a->ldc < a->N)
+  const bool silu = (a->flags & SLM_W4_SILU_MUL) != 0;
+  if (!aligned16(a->a) || !aligned16(a->wq) || a->lda % 8 || a->lda < a->K ||
+      a->ldc < (silu ? a->N / 2 : a->N))
     return SLM_ERR_ALIGNMENT;
   if ((pl.part_bytes + pl.aperm_bytes) > 0 &&
       (!a->workspace || a->workspace_bytes < pl.part_bytes + pl.aperm_bytes))
@@ -696,6 +782,7 @@ SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream) {
   kp.n_chunks = (int)(a->K / W4_KC);
   kp.split_k = pl.split_k; kp.chunks_per_split = pl.chunks_per_split;
   kp.n_mblocks = pl.n_mblocks; kp.n_nblocks = pl.n_nblocks;
+  kp.silu = silu ? 1 : 0;
   if (pl.gemv)
     launch_gemv(kp, a->dtype, pl.ng, st);
   else if (pl.small)
@@ -709,9 +796,15 @@ SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream) {
   rc = hip_check_launch();
   if (rc != SLM_OK) return rc;
   if (pl.split_k > 1 && !((a->flags & SLM_W4_DEFER_REDUCE) && !a->bias)) {
-    const int64_t n4 = a->M * a->N / 4;
+    const int64_t n4 = a->M * (silu ? a->N / 2 : a->N) / 4;
     const dim3 grid((unsigned)((n4 + 255) / 256)), blk(256);
-    if (a->dtype == SLM_BF16)
+    if (silu && a->dtype == SLM_BF16)
+      hipLaunchKernelGGL(w4_splitk_reduce_silu_kernel<bf16_tag>, grid, blk, 0, st, kp.part, a->bias,
+                         a->c, a->M, a->N, a->ldc, pl.split_k);
+    else if (silu)
+      hipLaunchKernelGGL(w4_splitk_reduce_silu_kernel<f16_tag>, grid, blk, 0, st, kp.part, a->bias,
+                         a->c, a->M, a->N, a->ldc, pl.split_k);
+    else if (a->dtype == SLM_BF16)
       hipLaunchKernelGGL(w4_splitk_reduce_kernel<bf16_tag>, grid, blk, 0, st, kp.part, a->bias, a->c,
                          a->M, a->N, a->ldc, pl.split_k);
     else

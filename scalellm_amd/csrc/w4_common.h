@@ -88,6 +88,7 @@ struct GemmKParams {
   int split_k;
   int chunks_per_split;
   int n_mblocks, n_nblocks;
+  int silu;  // SLM_W4_SILU_MUL: column tiles are (gate, up) pairs, c is [M, N/2]
 };
 
 template <typename T>
@@ -106,6 +107,50 @@ struct Mfma<f16_tag> {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
 };
+
+// SLM_W4_SILU_MUL epilogue of the C^T-accumulator kernels (w4_ws.hip, w4_xl.hip; split_k == 1):
+// the wave's two adjacent column tiles t0 (even: gate) and t0 + 1 (up) sit in the same lane at the
+// same (i, r), so the pair never leaves its registers.  Lane = token row0 + 32 i; the 16 values
+// are the columns (r & 3) + 8 (r >> 2) + 4 (lane >> 5): four consecutive outputs per r >> 2.
+template <typename T>
+__device__ __forceinline__ void store_ct_silu_pair(const GemmKParams& p, const f32x16 (&acc)[2][4],
+                                                   const int64_t t0, const int64_t row0,
+                                                   const int lane) {
+  if ((t0 + 1) * 32 >= p.N) return;
+  const bool wide = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.c) & 7) == 0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t gcol = t0 * 32 + 8 * q + 4 * (lane >> 5);
+    const int64_t ocol = (t0 >> 1) * 32 + 8 * q + 4 * (lane >> 5);
+    float bg[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      const uint16_t* bp = reinterpret_cast<const uint16_t*>(p.bias) + gcol;
+      const u32x2 g = *reinterpret_cast<const u32x2*>(bp);
+      const u32x2 u = *reinterpret_cast<const u32x2*>(bp + 32);
+      bg[0] = lo_f32<T>(g.x); bg[1] = hi_f32<T>(g.x); bg[2] = lo_f32<T>(g.y); bg[3] = hi_f32<T>(g.y);
+      bu[0] = lo_f32<T>(u.x); bu[1] = hi_f32<T>(u.x); bu[2] = lo_f32<T>(u.y); bu[3] = hi_f32<T>(u.y);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t row = row0 + i * 32;
+      if (row >= p.M) continue;
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        o[e] = silu_mul_acc<T>(acc[0][i][4 * q + e] + bg[e], acc[1][i][4 * q + e] + bu[e]);
+      uint16_t* dst = reinterpret_cast<uint16_t*>(p.c) + row * p.ldc + ocol;
+      u32x2 w;
+      w.x = pack2<T>(o[0], o[1]);
+      w.y = pack2<T>(o[2], o[3]);
+      if (wide) {
+        *reinterpret_cast<u32x2*>(dst) = w;
+      } else {
+        dst[0] = (uint16_t)(w.x & 0xffffu); dst[1] = (uint16_t)(w.x >> 16);
+        dst[2] = (uint16_t)(w.y & 0xffffu); dst[3] = (uint16_t)(w.y >> 16);
+      }
+    }
+  }
+}
 
 constexpr int W4_KC = 128;  // K granularity of the plan (split-K units, LDS chunk of the small-M kernels)
 

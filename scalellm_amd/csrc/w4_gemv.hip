@@ -34,6 +34,7 @@ struct GemvParams {
   int gs_shift;  // log2(group size); 30 = per-channel
   int tw, ks;    // column tiles x K slices per workgroup (tw * ks = 8)
   int n64;       // K / 64
+  int silu;      // SLM_W4_SILU_MUL: tw is even, tiles (2j, 2j+1) = (gate, up), c is [M, N/2]
 };
 
 constexpr int GV_RING = 8;  // weight ring depth (64-deep chunks per wave)
@@ -209,6 +210,26 @@ __global__ void __launch_bounds__(512) w4a16_gemv_kernel(const GemvParams p) {
     for (int m = 0; m < MT; ++m) red[(wave * MT + m) * 32 + lane] = acc[m];
   }
   __syncthreads();
+  if (p.silu) {
+    if (ks_i == 0 && nvalid && lane < 32 && !(tw_i & 1)) {
+      const int64_t gcol = nt * 32 + lane, ocol = (nt >> 1) * 32 + lane;
+      const uint16_t* bias = reinterpret_cast<const uint16_t*>(p.bias);
+      const float bg = bias ? lo_f32<T>((uint32_t)bias[gcol]) : 0.f;
+      const float bu = bias ? lo_f32<T>((uint32_t)bias[gcol + 32]) : 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        float g = 0.f, u = 0.f;
+        for (int k = 0; k < p.ks; ++k) {
+          g += red[((k * p.tw + tw_i) * MT + m) * 32 + lane];
+          u += red[((k * p.tw + tw_i + 1) * MT + m) * 32 + lane];
+        }
+        if (m < p.M)
+          reinterpret_cast<uint16_t*>(p.c)[(int64_t)m * p.ldc + ocol] =
+              pack1<T>(silu_mul_acc<T>(g + bg, u + bu));
+      }
+    }
+    return;
+  }
   if (ks_i == 0 && nvalid && lane < 32) {
     const int64_t ncol = nt * 32 + lane;
     float bv = 0.f;
@@ -262,6 +283,10 @@ void launch_gemv(const GemmKParams& kp, int dtype, int ng, hipStream_t st) {
   const int64_t tiles = kp.N / 32;
   int ks = 8;
   while (ks > 1 && (gp.n64 / ks < 4 || tiles * ks / 8 > 2048)) ks >>= 1;
+  const int forced_ks = tune_get(TUNE_W4_GEMV_KS, 0);
+  if (forced_ks == 1 || forced_ks == 2 || forced_ks == 4 || forced_ks == 8) ks = forced_ks;
+  gp.silu = kp.silu;
+  if (kp.silu && ks == 8) ks = 4;  // a (gate, up) tile pair has to share the workgroup: tw >= 2
   gp.ks = ks;
   gp.tw = 8 / ks;
   const int n_wgs = (int)((tiles + gp.tw - 1) / gp.tw);

@@ -232,13 +232,33 @@ __global__ void __launch_bounds__(256, 2) w4a16_gemm_small_kernel(const GemmKPar
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  if (!nvalid) return;
   const int64_t ncol = nt * 32 + (lane & 31);
   float bv = 0.f;
   if (p.split_k == 1 && p.bias) {
     const uint16_t braw = reinterpret_cast<const uint16_t*>(p.bias)[ncol];
     bv = lo_f32<T>((uint32_t)braw);
   }
+  if (p.silu && p.split_k == 1) {
+    // SLM_W4_SILU_MUL: waves (0, 1) and (2, 3) hold a (gate, up) tile pair.  The up wave hands its
+    // T-rounded tile to the gate wave through the (now idle) A buffers; same lane, same r.
+    uint16_t* ex = reinterpret_cast<uint16_t*>(smem) + (wave >> 1) * 1024;
+    if (wave & 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ex[r * 64 + lane] = pack1<T>(acc[r] + bv);
+    }
+    __syncthreads();
+    if ((wave & 1) || !nvalid) return;
+    const int64_t ocol = (nt >> 1) * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const float g = lo_f32<T>((uint32_t)pack1<T>(acc[r] + bv));
+      const float u = lo_f32<T>((uint32_t)ex[r * 64 + lane]);
+      if (row < p.M) reinterpret_cast<uint16_t*>(p.c)[row * p.ldc + ocol] = pack1<T>(silu_mul1(g, u));
+    }
+    return;
+  }
+  if (!nvalid) return;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int64_t row = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);

@@ -300,6 +300,10 @@ __global__ void __launch_bounds__(512, 2) w4a16_gemm_ws_kernel(const GemmKParams
   // accumulator tile is C^T: this lane holds token m = tile row base + (lane & 31) and the 16
   // columns n = 32 t + (r & 3) + 8 (r >> 2) + 4 (lane >> 5) -- four consecutive columns per
   // r >> 2, i.e. one 8-byte (bf16/fp16) or 16-byte (fp32 partial) store instead of four 2-byte ones.
+  if (p.silu && p.split_k == 1) {
+    store_ct_silu_pair<T>(p, acc, (int64_t)nb * 4 + nh * 2, m0 + mh * 128 + (lane & 31), lane);
+    return;
+  }
   const bool wide = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.c) & 7) == 0);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {

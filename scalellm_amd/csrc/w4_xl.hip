@@ -219,6 +219,10 @@ __global__ void __launch_bounds__(512, 2) w4a16_gemm_xl_kernel(const GemmKParams
   }
 
   // ---- epilogue (C^T accumulators: lane = token, 4 consecutive columns per r >> 2) ----
+  if (p.silu && p.split_k == 1) {
+    store_ct_silu_pair<T>(p, acc, (int64_t)nb * 8 + nq * 2, m0 + mh * 128 + (lane & 31), lane);
+    return;
+  }
   const bool wide = ((p.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.c) & 7) == 0);
 #pragma unroll
   for (int j = 0; j < 2; ++j) {

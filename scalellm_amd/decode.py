@@ -94,8 +94,11 @@ class LlamaDecodeStep:
                  parallel_args: Optional[ParallelArgs] = None, quant_method: str = "awq",
                  group_size: int = 128, dtype=torch.bfloat16, device="cuda", seed: int = 0,
                  kv_fill: str = "none", custom_allreduce=None, keep_checkpoint: bool = False,
-                 gptq_sym: bool = False):
+                 gptq_sym: bool = False, fuse_silu: bool = True):
         pa = parallel_args or ParallelArgs()
+        # fuse_silu: the merged gate_up weight is packed paired and SiLU*mul runs in the GEMM
+        # epilogue (identical bits; False keeps the separate kernels.silu_and_mul launch)
+        fuse_silu = fuse_silu and (shape.intermediate // pa.world_size) % 32 == 0
         # keep_checkpoint: retain this rank's CHECKPOINT-format tensors (self.ckpt[layer][name]) so a
         # parity test can rebuild the same model from them on the CPU oracle
         self.ckpt = [] if keep_checkpoint else None
@@ -129,7 +132,8 @@ class LlamaDecodeStep:
             L = {}
             L["qkv"] = ColumnParallelQLinear(H, qkv_n * tp, False, qa, False, pa, dtype, self.device)
             L["o"] = RowParallelQLinear(q_full, H, False, qa, True, pa, dtype, self.device)
-            L["gate_up"] = ColumnParallelQLinear(H, 2 * inter, False, qa, False, pa, dtype, self.device)
+            L["gate_up"] = ColumnParallelQLinear(H, 2 * inter, False, qa, False, pa, dtype, self.device,
+                                                 act_mul="silu" if fuse_silu else None)
             L["down"] = RowParallelQLinear(inter, H, False, qa, True, pa, dtype, self.device)
             full = _rand_int4_linear(gen, H, q_full + 2 * kv_full, group_size, quant_method, dtype, self.device,
                                      sym=gptq_sym and quant_method == "gptq")
@@ -171,7 +175,7 @@ class LlamaDecodeStep:
         T = max_batch_tokens
         e = lambda *s: torch.empty(*s, dtype=dtype, device=self.device)  # noqa: E731
         self.buf = dict(resid=e(T, H), normed=e(T, H), qkv=e(T, qkv_n), attn=e(T, self.n_heads, D),
-                        o=e(T, H), gate_up=e(T, 2 * shape.intermediate // tp),
+                        o=e(T, H), gate_up=None if fuse_silu else e(T, 2 * shape.intermediate // tp),
                         act=e(T, shape.intermediate // tp), down=e(T, H))
         if kv_fill != "none":
             self.fill_kv(kv_fill, gen)
@@ -259,8 +263,11 @@ class LlamaDecodeStep:
             defer = pa.world_size == 1 and os.environ.get("SLM_DEFER_SPLITK", "1") != "0"
             delta = L["o"].forward(attn, out=o_buf, reduce=False, defer_splitk=defer)
             reduce_add_norm(0, delta, L["post_norm"], L["o"].deferred if defer else None)
-            gu = L["gate_up"].forward(normed, out=b["gate_up"][:T])
-            kernels.silu_and_mul(b["act"][:T], gu)
+            if L["gate_up"].paired:  # SiLU*mul in the GEMM epilogue
+                L["gate_up"].forward(normed, out=b["act"][:T])
+            else:
+                gu = L["gate_up"].forward(normed, out=b["gate_up"][:T])
+                kernels.silu_and_mul(b["act"][:T], gu)
             delta = L["down"].forward(b["act"][:T], out=down_buf, reduce=False, defer_splitk=defer)
             # the NEXT block's input norm (or the final norm) consumes this reduction
             nxt = self.layers[li + 1]["in_norm"] if li + 1 < len(self.layers) else self.final_norm

@@ -293,12 +293,15 @@ class PackedW4:
     (qlinear_awq_marlin_impl.cpp:99-125,232-235; qlinear_gptq_marlin_impl.cpp:41-71,181-184).
     """
 
-    def __init__(self, wq, sz, perm, K, N, group_size, dtype):
+    def __init__(self, wq, sz, perm, K, N, group_size, dtype, paired=False):
         self.wq, self.sz, self.perm = wq, sz, perm
         self.K, self.N, self.group_size, self.dtype = K, N, group_size, dtype
+        # paired: a merged [gate | up] weight whose packed column tiles alternate gate / up
+        # (SLM_W4_PAIRED) -- the form gptq_gemm(..., silu_mul=True) needs
+        self.paired = paired
 
 
-def _prepack(fmt: int, qweight, qzeros, scales, perm, K, N, group_size) -> PackedW4:
+def _prepack(fmt: int, qweight, qzeros, scales, perm, K, N, group_size, paired=False) -> PackedW4:
     L = _lib.lib()
     _require_gpu(qweight, qzeros, scales, perm)
     for t in (qweight, qzeros):
@@ -316,28 +319,35 @@ def _prepack(fmt: int, qweight, qzeros, scales, perm, K, N, group_size) -> Packe
     sz = torch.empty(nb_sz // 4, dtype=torch.int32, device=qweight.device)
     if perm is not None and (perm.dtype != torch.int32 or not perm.is_contiguous()):
         raise SlmError("perm must be contiguous int32 [K]")
+    if paired:
+        if N % 64:
+            raise SlmError(f"paired (gate | up) prepack needs N % 64 == 0, got N={N}")
+        fmt |= _lib.SLM_W4_PAIRED
     check(L.slm_w4_prepack(fmt, qweight.data_ptr(), qzeros.data_ptr(), scales.data_ptr(),
                            perm.data_ptr() if perm is not None else None, K, N, gs,
                            _dtype_code(scales), wq.data_ptr(), sz.data_ptr(), _stream()),
           "slm_w4_prepack")
-    return PackedW4(wq, sz, perm, K, N, gs, scales.dtype)
+    return PackedW4(wq, sz, perm, K, N, gs, scales.dtype, paired)
 
 
 def awq_repack(qweight: torch.Tensor,  # [K, N/8] int32, AWQ interleave
                qzeros: torch.Tensor,   # [G, N/8] int32, AWQ interleave
                scales: torch.Tensor,   # [G, N] fp16/bf16
-               group_size: int) -> PackedW4:
+               group_size: int, paired: bool = False) -> PackedW4:
     """Mirror of marlin::awq_repack (+ the host-side zero/scale permutes of
-    qlinear_awq_marlin_impl.cpp:34-125), from the AWQ checkpoint format."""
+    qlinear_awq_marlin_impl.cpp:34-125), from the AWQ checkpoint format.
+
+    paired: the tensors are a merged [gate | up] weight (multi_parallel_linear.cpp:14-41); pack
+    the two halves interleaved by 32-column tile so the GEMM can fuse SiLU*mul (silu_mul=True)."""
     K, N = qweight.size(0), qweight.size(1) * 8
-    return _prepack(_lib.SLM_W4_AWQ, qweight, qzeros, scales, None, K, N, group_size)
+    return _prepack(_lib.SLM_W4_AWQ, qweight, qzeros, scales, None, K, N, group_size, paired)
 
 
 def gptq_repack(qweight: torch.Tensor,  # [K/8, N] int32
                 qzeros: torch.Tensor,   # [G, N/8] int32 (zero = stored + 1)
                 scales: torch.Tensor,   # [G, N]
                 group_size: int,
-                g_idx: Optional[torch.Tensor] = None) -> PackedW4:
+                g_idx: Optional[torch.Tensor] = None, paired: bool = False) -> PackedW4:
     """Mirror of marlin::gptq_repack (+ qlinear_gptq_marlin_impl.cpp:41-71): act-order
     checkpoints (g_idx not monotone) are handled like the reference: rows sorted by group
     (perm = argsort(g_idx)), the activation columns gathered by the same perm at GEMM time."""
@@ -354,14 +364,17 @@ def gptq_repack(qweight: torch.Tensor,  # [K/8, N] int32
             if not torch.equal(g_idx.to(torch.int64)[perm64], trivial):
                 raise SlmError("act-order g_idx with uneven groups is not supported")
             perm = perm64.to(torch.int32).contiguous()
-    return _prepack(_lib.SLM_W4_GPTQ, qweight, qzeros, scales, perm, K, N, gs)
+    return _prepack(_lib.SLM_W4_GPTQ, qweight, qzeros, scales, perm, K, N, gs, paired)
 
 
-def _gemm_args(a, packed: PackedW4, c, bias) -> W4GemmArgs:
+def _gemm_args(a, packed: PackedW4, c, bias, silu_mul=False) -> W4GemmArgs:
     _require_gpu(a, c, bias)
     if a.dim() != 2 or c.dim() != 2 or a.stride(1) != 1 or c.stride(1) != 1:
         raise SlmError("A [M, K] and C [M, N] must be 2-D with contiguous rows")
-    if a.size(1) != packed.K or c.size(1) != packed.N or a.size(0) != c.size(0):
+    if silu_mul and not packed.paired:
+        raise SlmError("silu_mul=True needs weights packed with paired=True (gate | up tiles interleaved)")
+    n_out = packed.N // 2 if silu_mul else packed.N
+    if a.size(1) != packed.K or c.size(1) != n_out or a.size(0) != c.size(0):
         raise SlmError("GEMM shape mismatch")
     if a.dtype != packed.dtype or c.dtype != packed.dtype:
         raise SlmError("activation / output dtype must match the prepacked scales dtype")
@@ -379,7 +392,8 @@ def _gemm_args(a, packed: PackedW4, c, bias) -> W4GemmArgs:
 
 
 def gptq_gemm(a: torch.Tensor, packed: PackedW4, c: torch.Tensor,
-              bias: Optional[torch.Tensor] = None, defer_reduce: bool = False) -> DeferredPartials:
+              bias: Optional[torch.Tensor] = None, defer_reduce: bool = False,
+              silu_mul: bool = False) -> DeferredPartials:
     """Mirror of marlin::gptq_gemm (marlin.h:17-25): C[M,N] = A[M,K] . dequant(W) (+ bias),
     fp32 accumulate, written into the pre-allocated `c`.  AWQ and GPTQ share it, as in the
     reference (has_zp true/false): zero points live in the prepacked scale/zero table.
@@ -387,11 +401,19 @@ def gptq_gemm(a: torch.Tensor, packed: PackedW4, c: torch.Tensor,
     defer_reduce: when the call is split over K, leave the fp32 partial sums in a dedicated
     device buffer for the consumer (rms_norm(..., partials=handle)) instead of reducing them into
     `c`.  Returns a DeferredPartials handle: truthy (int(handle) = slab count >= 2) when slabs
-    were left behind and `c` was NOT written, falsy when `c` was written as usual."""
+    were left behind and `c` was NOT written, falsy when `c` was written as usual.
+
+    silu_mul: `packed` is a paired (gate | up) weight and `c` is [M, N/2]: the epilogue applies
+    kernel::act_and_mul (activation_kernels.cu:84) -- c = silu(gate) * up, bit-identical to the
+    unfused GEMM followed by silu_mul()."""
     L = _lib.lib()
-    g = _gemm_args(a, packed, c, bias)
+    if silu_mul and defer_reduce:
+        raise SlmError("silu_mul and defer_reduce cannot be combined")
+    g = _gemm_args(a, packed, c, bias, silu_mul)
     if g.M == 0:
         return DeferredPartials()
+    if silu_mul:
+        g.flags = _lib.SLM_W4_SILU_MUL
     deferred = 0
     if defer_reduce:
         g.flags = _lib.SLM_W4_DEFER_REDUCE

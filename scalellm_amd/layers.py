@@ -153,6 +153,7 @@ class _QLinearBase:
         self.bias: Optional[torch.Tensor] = None
         self._ckpt: Dict[str, torch.Tensor] = {}
         self._packed: Optional[kernels.PackedW4] = None
+        self.paired = False  # merged [gate | up] weight packed for the fused SiLU*mul epilogue
 
     # checkpoint-format tensors for THIS rank's shard
     def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
@@ -171,12 +172,17 @@ class _QLinearBase:
         scales = c["scales"].to(self.dtype).contiguous()
         if self.quant_args.quant_method == "awq":
             self._packed = kernels.awq_repack(c["qweight"], c["qzeros"], scales,
-                                              self.quant_args.group_size)
+                                              self.quant_args.group_size, paired=self.paired)
         else:
             self._packed = kernels.gptq_repack(c["qweight"], c["qzeros"], scales,
-                                               self.quant_args.group_size, c.get("g_idx"))
+                                               self.quant_args.group_size, c.get("g_idx"),
+                                               paired=self.paired)
         if self.has_bias:
             self.bias = c["bias"].to(self.dtype).contiguous()
+            if self.paired:  # the bias follows the packed column order: gate / up 32-column tiles alternate
+                n = self.bias.numel()
+                self.bias = torch.stack([self.bias[:n // 2].view(-1, 32), self.bias[n // 2:].view(-1, 32)],
+                                        dim=1).reshape(-1).contiguous()
         self._ckpt = {}
 
     def _gemm(self, x: torch.Tensor, bias: Optional[torch.Tensor],
@@ -184,6 +190,11 @@ class _QLinearBase:
         if self._packed is None:
             self._repack()
         x2 = x.reshape(-1, x.size(-1))
+        if self.paired:
+            if out is None:
+                out = torch.empty(x2.size(0), self._packed.N // 2, dtype=x.dtype, device=x.device)
+            kernels.gptq_gemm(x2, self._packed, out, bias, silu_mul=True)
+            return out
         if out is None:
             out = torch.empty(x2.size(0), self._packed.N, dtype=x.dtype, device=x.device)
         # truthy: `out` was NOT written, fp32 split-K slabs wait in the deferred buffer for
@@ -198,9 +209,18 @@ class ColumnParallelQLinear(_QLinearBase):
     in_features / out_features are the FULL sizes; this rank holds out_features / world_size."""
 
     def __init__(self, in_features, out_features, bias, quant_args, gather_output,
-                 parallel_args, dtype, device):
+                 parallel_args, dtype, device, act_mul: Optional[str] = None):
+        """act_mul="silu": the weight is the MLP's merged [gate | up] projection
+        (multi_parallel_linear.cpp:14-41) and forward returns act_and_mul of it,
+        silu(gate) * up of width out_features / 2 per rank (activation_kernels.cu:84), computed in
+        the GEMM epilogue -- bit-identical to forward + kernels.silu_and_mul, one launch less."""
         super().__init__(in_features, out_features, bias, quant_args, parallel_args, dtype, device)
         self.gather_output = gather_output
+        if act_mul not in (None, "silu"):
+            raise ValueError(f"unsupported fused activation {act_mul!r}")
+        self.paired = act_mul == "silu"
+        if self.paired and gather_output:
+            raise ValueError("act_mul needs the sharded output (gather_output=False)")
 
     def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self._packed is None:

@@ -171,8 +171,9 @@ def make_quant_case(seed, K, N, group_size, fmt, dtype_bits="bf16", act_order=Fa
     return d
 
 
-def pack_case(case, bits="bf16", device="cuda"):
-    """make_quant_case() output -> scalellm_amd.kernels.PackedW4 on `device` (GPU tests only)."""
+def pack_case(case, bits="bf16", device="cuda", paired=False):
+    """make_quant_case() output -> scalellm_amd.kernels.PackedW4 on `device` (GPU tests only).
+    paired: treat the layer as a merged [gate | up] weight (SLM_W4_PAIRED)."""
     import torch
     from scalellm_amd import kernels
     dt = torch.bfloat16 if bits == "bf16" else torch.float16
@@ -180,6 +181,6 @@ def pack_case(case, bits="bf16", device="cuda"):
     qzeros = torch.from_numpy(case["qzeros"]).to(device)
     scales = torch.from_numpy(case["scales_bits"].view(np.int16)).to(device).view(dt)
     if case["fmt"] == "awq":
-        return kernels.awq_repack(qweight, qzeros, scales, case["group_size"])
+        return kernels.awq_repack(qweight, qzeros, scales, case["group_size"], paired=paired)
     g_idx = torch.from_numpy(case["g_idx"]).to(device) if case["g_idx"] is not None else None
-    return kernels.gptq_repack(qweight, qzeros, scales, case["group_size"], g_idx)
+    return kernels.gptq_repack(qweight, qzeros, scales, case["group_size"], g_idx, paired=paired)
