@@ -405,18 +405,33 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const AttnKParams p, 
     if (rows < p.rows_lo || rows >= p.rows_hi) return;
   }
   const float* ml = p.ml_part + item * p.n_splits * 2;
+  // every load below is UNCONDITIONAL (index clamped, result masked afterwards): a load inside a
+  // branch makes hipcc wait for it at the join, which turns independent loads into a chain of HBM
+  // round trips (tools/probes/experiments/attn_in_kernel_combine.md)
+  const int s_last = p.n_splits - 1;
   float mreg[4], lreg[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float2 v = *reinterpret_cast<const float2*>(ml + 2 * min(lane + 64 * i, s_last));
+    mreg[i] = v.x;
+    lreg[i] = v.y;
+  }
+  const int LPS = 1 << lps_shift;      // lanes per split (>= head_dim/4)
+  const int phase = lane >> lps_shift;  // split phase of this lane
+  const int n_phase = 64 >> lps_shift;
+  const int d0 = (lane & (LPS - 1)) * 4;
+  const bool actd = d0 < p.head_dim;  // idle dim lanes (head_dim < 4 LPS) re-read dims 0..3
+  const float* op = p.o_part + item * p.n_splits * p.head_dim + (actd ? d0 : 0);
+  // first batch of O loads: issued BEFORE the weights are known (they do not depend on them)
+  constexpr int NFIRST = 8;
+  f32x4 first[NFIRST];
+#pragma unroll
+  for (int i = 0; i < NFIRST; ++i)
+    first[i] = *reinterpret_cast<const f32x4*>(op + (int64_t)min(phase + i * n_phase, s_last) * p.head_dim);
   float M = ATTN_M_INIT;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int s = lane + 64 * i;
-    mreg[i] = ATTN_M_INIT;
-    lreg[i] = 0.f;
-    if (s < p.n_splits) {
-      const float2 v = *reinterpret_cast<const float2*>(ml + 2 * s);
-      mreg[i] = v.x;
-      lreg[i] = v.y;
-    }
+    if (lane + 64 * i > s_last) lreg[i] = 0.f;
     if (lreg[i] > 0.f) M = fmaxf(M, mreg[i]);
   }
 #pragma unroll
@@ -432,25 +447,20 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const AttnKParams p, 
   for (int d = 1; d < 64; d <<= 1) L += __shfl_xor(L, d, 64);
   __builtin_amdgcn_wave_barrier();  // wsm row is wave-private; LDS ops of one wave are ordered
 
-  const int LPS = 1 << lps_shift;      // lanes per split (>= head_dim/4)
-  const int phase = lane >> lps_shift;  // split phase of this lane
-  const int n_phase = 64 >> lps_shift;
-  const int d0 = (lane & (LPS - 1)) * 4;
-  const bool actd = d0 < p.head_dim;
-  const float* op = p.o_part + item * p.n_splits * p.head_dim + d0;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (actd) {
-    int s = phase;
-    for (; s + 3 * n_phase < p.n_splits; s += 4 * n_phase) {
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(op + (int64_t)s * p.head_dim);
-      const f32x4 a1 = *reinterpret_cast<const f32x4*>(op + (int64_t)(s + n_phase) * p.head_dim);
-      const f32x4 a2 = *reinterpret_cast<const f32x4*>(op + (int64_t)(s + 2 * n_phase) * p.head_dim);
-      const f32x4 a3 = *reinterpret_cast<const f32x4*>(op + (int64_t)(s + 3 * n_phase) * p.head_dim);
-      acc += wsm[wv][s] * a0 + wsm[wv][s + n_phase] * a1 + wsm[wv][s + 2 * n_phase] * a2 +
-             wsm[wv][s + 3 * n_phase] * a3;
-    }
-    for (; s < p.n_splits; s += n_phase)
-      acc += wsm[wv][s] * *reinterpret_cast<const f32x4*>(op + (int64_t)s * p.head_dim);
+#pragma unroll
+  for (int i = 0; i < NFIRST; ++i) {
+    const int s = phase + i * n_phase;
+    acc += (s <= s_last ? wsm[wv][min(s, COMBINE_MAX_SPLITS - 1)] : 0.f) * first[i];
+  }
+  for (int s = phase + NFIRST * n_phase; s <= s_last; s += 4 * n_phase) {
+    const int s1 = s + n_phase, s2 = s + 2 * n_phase, s3 = s + 3 * n_phase;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(op + (int64_t)s * p.head_dim);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(op + (int64_t)min(s1, s_last) * p.head_dim);
+    const f32x4 a2 = *reinterpret_cast<const f32x4*>(op + (int64_t)min(s2, s_last) * p.head_dim);
+    const f32x4 a3 = *reinterpret_cast<const f32x4*>(op + (int64_t)min(s3, s_last) * p.head_dim);
+    acc += wsm[wv][s] * a0 + (s1 <= s_last ? wsm[wv][s1] : 0.f) * a1 +
+           (s2 <= s_last ? wsm[wv][s2] : 0.f) * a2 + (s3 <= s_last ? wsm[wv][s3] : 0.f) * a3;
   }
   for (int d = LPS; d < 64; d <<= 1) {
     acc.x += __shfl_xor(acc.x, d, 64);
