@@ -164,13 +164,27 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
   const uint32_t k_sb = (uint32_t)(2 * p.k_ss), v_sb = (uint32_t)(2 * p.v_ss);
 
   u32x4 kreg[ITEMS], vreg[ITEMS];
-  auto tile_load = [&](int kt0) {
+  // AHEAD: the block-table lookups (a global load the K/V addresses depend on) run one tile ahead
+  // of the K/V loads that use them: prefill 423 -> 447 TFLOP/s, chunked 678 -> 731.  The one-wave
+  // (verify) form is at its 256-VGPR cap and spills with the 8 extra registers (335 -> 401 us), so
+  // it looks the slots up right before its loads.
+  constexpr bool AHEAD = NW > 1;
+  int sreg[ITEMS];  // cache slots of the next tile_load
+  auto slot_load = [&](int kt0) {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
-      const int idx = tid + nthreads * i;
-      const int r = idx / NSLOT, sl = idx % NSLOT;
+      const int r = (tid + nthreads * i) / NSLOT;
       const int row = min(kt0 + r, kv_len - 1);  // clamp: masked below, must stay in bounds
-      const int slot = p.bt[bcu0 + (row >> p.block_shift)] + (row & p.block_mask);
+      sreg[i] = p.bt[bcu0 + (row >> p.block_shift)] + (row & p.block_mask);
+    }
+  };
+  // K/V rows of the tile whose slots slot_load() fetched; then the slots of tile `kt_next`, so the
+  // table lookup (a dependent global load) is off the critical path of the NEXT tile's K/V loads
+  auto tile_load = [&](int kt_next) {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int sl = (tid + nthreads * i) % NSLOT;
+      const int slot = sreg[i];
       const u32x4* kp_ = reinterpret_cast<const u32x4*>(kbase + (uint64_t)(uint32_t)slot * k_sb + 16 * sl);
       const u32x4* vp_ = reinterpret_cast<const u32x4*>(vbase + (uint64_t)(uint32_t)slot * v_sb + 16 * sl);
       if constexpr (NW == 1) {
@@ -184,6 +198,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
         vreg[i] = *vp_;
       }
     }
+    if constexpr (AHEAD) slot_load(kt_next);
   };
   auto tile_store = [&]() {
 #pragma unroll
@@ -203,7 +218,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
 
   if constexpr (PF) {
     if (wg_lo < wg_hi_s) {
-      tile_load(wg_lo);
+      slot_load(wg_lo);
+      tile_load(min(wg_lo + TILE_KV, wg_hi_s - 1));
       tile_store();
     }
     __syncthreads();
@@ -211,9 +227,11 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
   for (int kt0 = wg_lo; kt0 < wg_hi_s; kt0 += TILE_KV) {
     if constexpr (PF) {
       // next tile's rows travel HBM -> registers while this tile is consumed from LDS
-      tile_load(min(kt0 + TILE_KV, wg_hi_s - 1));
+      if constexpr (!AHEAD) slot_load(min(kt0 + TILE_KV, wg_hi_s - 1));
+      tile_load(min(kt0 + 2 * TILE_KV, wg_hi_s - 1));
     } else {
       __syncthreads();  // previous tile fully consumed
+      slot_load(kt0);
       tile_load(kt0);
       tile_store();
       __syncthreads();
