@@ -272,6 +272,20 @@ SLM_API int slm_rope_kv_append(void* q /* [T, n_heads, D] in place */, int64_t q
                                void* key_cache, void* value_cache,
                                int64_t n_tokens, int32_t n_heads, int32_t n_kv_heads,
                                int32_t head_dim, int32_t dtype, void* stream);
+/* The same with q / k / v given as the split-K partial sums the fused qkv GEMM left behind
+ * (SLM_W4_DEFER_REDUCE; GEMM row = [q | k | v], N = (n_heads + 2 n_kv_heads) * head_dim):
+ * x := T(sum_s partials[s][t][col]) in the reduce kernel's own order, so the result is
+ * bit-identical to "reduce, then slm_rope_kv_append" with one launch less.  q, k, v are OUTPUTS
+ * here (q rotated, k rotated, v), k / v also go to their cache slot when slot_ids != NULL.
+ * Needs cos_sin, rot_dim % 8 == 0, head_dim % 4 == 0 (SLM_ERR_UNSUPPORTED otherwise: reduce first). */
+SLM_API int slm_rope_kv_append_splitk(const float* partials /* [n_splits, T, N] */, int32_t n_splits,
+                                      void* q, int64_t q_token_stride, void* k, int64_t k_token_stride,
+                                      void* v, int64_t v_token_stride, const int32_t* positions,
+                                      const void* cos_sin, int32_t cos_sin_is_f32, int32_t rot_dim,
+                                      int32_t interleaved, const int32_t* slot_ids /* or NULL */,
+                                      void* key_cache, void* value_cache, int64_t n_tokens,
+                                      int32_t n_heads, int32_t n_kv_heads, int32_t head_dim,
+                                      int32_t dtype, void* stream);
 SLM_API int slm_silu_mul(void* out /* [T, d] */, const void* x /* [T, 2d]: gate | up */,
                          int64_t n_tokens, int64_t d, int32_t dtype, void* stream);
 

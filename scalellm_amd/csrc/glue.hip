@@ -76,6 +76,18 @@ __global__ void __launch_bounds__(256) rms_norm_kernel(uint16_t* __restrict__ ou
   }
 }
 
+// (a, b) rotated by (cos, sin): ONE spelling for every RoPE kernel (explicit fma, so the compiler's
+// contraction choices cannot differ between them -- the split-K form must reproduce the plain one)
+__device__ __forceinline__ void rope_rot(const float a, const float b, const float c, const float s,
+                                         float& o0, float& o1) {
+  o0 = __builtin_fmaf(a, c, -(b * s));
+  o1 = __builtin_fmaf(b, c, a * s);
+  // fp32 results in registers before any conversion to T (otherwise fp16 callers may get a
+  // single-rounding v_fma_mixlo_f16 in one kernel and fma + convert in another)
+  asm("" : "+v"(o0));
+  asm("" : "+v"(o1));
+}
+
 // one workgroup per token.  Rotation pairs: non-interleaved (i, i + rot/2), interleaved (2i, 2i+1)
 // (src/kernels/pos_embedding_kernels.cu:9-30).  cos_sin row = [cos(rot/2) | sin(rot/2)].
 template <typename T, typename CS>
@@ -104,8 +116,10 @@ __global__ void __launch_bounds__(256) rope_kv_append_kernel(
       uint16_t* p = qt + (int64_t)h * head_dim;
       const float a = lo_f32<T>((uint32_t)p[i0]), b = lo_f32<T>((uint32_t)p[i1]);
       const float c = csval(r), s = csval(half + r);
-      p[i0] = pack1<T>(a * c - b * s);
-      p[i1] = pack1<T>(b * c + a * s);
+      float r0, r1;
+      rope_rot(a, b, c, s, r0, r1);
+      p[i0] = pack1<T>(r0);
+      p[i1] = pack1<T>(r1);
     }
     // K: in place + cache slot
     uint16_t* kt = k + tok * k_ts;
@@ -115,7 +129,9 @@ __global__ void __launch_bounds__(256) rope_kv_append_kernel(
       uint16_t* p = kt + (int64_t)h * head_dim;
       const float a = lo_f32<T>((uint32_t)p[i0]), b = lo_f32<T>((uint32_t)p[i1]);
       const float c = csval(r), s = csval(half + r);
-      const uint16_t o0 = pack1<T>(a * c - b * s), o1 = pack1<T>(b * c + a * s);
+      float r0, r1;
+      rope_rot(a, b, c, s, r0, r1);
+      const uint16_t o0 = pack1<T>(r0), o1 = pack1<T>(r1);
       p[i0] = o0;
       p[i1] = o1;
       if (slot >= 0) {
@@ -142,6 +158,98 @@ __global__ void __launch_bounds__(256) rope_kv_append_kernel(
     } else {
       for (int i = tid; i < row; i += 256) value_cache[slot * row + i] = vt[i];
     }
+  }
+}
+
+// The same operator with q / k / v given as the fp32 split-K partial sums the fused qkv GEMM left
+// behind (SLM_W4_DEFER_REDUCE): row t of the GEMM output is [q (n_heads D) | k (n_kv D) | v (n_kv D)]
+// and x = T(sum_s part[s][t][col]), summed in the split-K reduce kernel's order and rounded to T at
+// the same point, so the result is bit-identical to "reduce, then slm_rope_kv_append" -- minus the
+// reduce launch and one round trip of the qkv activations.  q is written rotated to `q` (attention
+// reads it there), k / v to `k` / `v` and to their cache slot.  A thread owns 4 + 4 values of one
+// head: dims [4u, 4u+4) and [half + 4u, ...) (non-interleaved pairs (i, i + half)) or the 8
+// consecutive dims [8u, 8u+8) (interleaved pairs (2i, 2i+1)): two 16-B loads per slab either way.
+template <typename T, typename CS>
+__global__ void __launch_bounds__(256) rope_kv_append_splitk_kernel(
+    const float* __restrict__ part, int n_splits, int64_t slab /* = n_tokens * N */, int64_t N,
+    uint16_t* __restrict__ q, int64_t q_ts, uint16_t* __restrict__ k, int64_t k_ts,
+    uint16_t* __restrict__ v, int64_t v_ts, const int* __restrict__ positions,
+    const CS* __restrict__ cos_sin, int rot_dim, int interleaved, const int* __restrict__ slot_ids,
+    uint16_t* __restrict__ key_cache, uint16_t* __restrict__ value_cache, int n_heads,
+    int n_kv_heads, int head_dim) {
+  const int64_t tok = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int half = rot_dim / 2;
+  const int64_t slot = slot_ids ? (int64_t)slot_ids[tok] : -1;
+  const int64_t row = (int64_t)n_kv_heads * head_dim;
+  const CS* cs = cos_sin + (int64_t)positions[tok] * rot_dim;
+  auto csval = [&](int i) -> float {
+    if constexpr (sizeof(CS) == 4) return (float)cs[i];
+    else return lo_f32<T>((uint32_t)cs[i]);
+  };
+  const float* prow = part + tok * N;
+  // T(sum over slabs) of 4 consecutive columns, as fp32 values that are exact in T
+  auto ld4 = [&](int64_t col, float (&x)[4]) {
+    const f32x4 s = splitk_sum4(prow + col, slab, n_splits);
+    x[0] = lo_f32<T>((uint32_t)pack1<T>(s.x)); x[1] = lo_f32<T>((uint32_t)pack1<T>(s.y));
+    x[2] = lo_f32<T>((uint32_t)pack1<T>(s.z)); x[3] = lo_f32<T>((uint32_t)pack1<T>(s.w));
+  };
+  auto st4 = [&](uint16_t* dst, const float (&x)[4]) {
+    u32x2 w;
+    w.x = pack2<T>(x[0], x[1]);
+    w.y = pack2<T>(x[2], x[3]);
+    *reinterpret_cast<u32x2*>(dst) = w;
+  };
+  const int upr = half / 4;                  // rotary units per head
+  const int n_rot_heads = n_heads + n_kv_heads;  // q heads, then k heads
+  for (int i = tid; i < n_rot_heads * upr; i += 256) {
+    const int h = i / upr, u = i % upr;
+    const bool is_k = h >= n_heads;
+    const int hh = is_k ? h - n_heads : h;
+    const int64_t col0 = (int64_t)h * head_dim;  // k heads follow the q heads in the GEMM row
+    const int da = interleaved ? 8 * u : 4 * u, db = interleaved ? 8 * u + 4 : half + 4 * u;
+    float a[4], b[4], oa[4], ob[4];
+    ld4(col0 + da, a);
+    ld4(col0 + db, b);
+    if (interleaved) {  // pairs (a0,a1) (a2,a3) (b0,b1) (b2,b3), pair index r = 4u + {0,1,2,3}
+      const float c0 = csval(4 * u), s0 = csval(half + 4 * u), c1 = csval(4 * u + 1), s1 = csval(half + 4 * u + 1);
+      const float c2 = csval(4 * u + 2), s2 = csval(half + 4 * u + 2), c3 = csval(4 * u + 3), s3 = csval(half + 4 * u + 3);
+      rope_rot(a[0], a[1], c0, s0, oa[0], oa[1]);
+      rope_rot(a[2], a[3], c1, s1, oa[2], oa[3]);
+      rope_rot(b[0], b[1], c2, s2, ob[0], ob[1]);
+      rope_rot(b[2], b[3], c3, s3, ob[2], ob[3]);
+    } else {            // pairs (a[e], b[e]), r = 4u + e
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        rope_rot(a[e], b[e], csval(4 * u + e), csval(half + 4 * u + e), oa[e], ob[e]);
+      }
+    }
+    uint16_t* dst = is_k ? k + tok * k_ts + (int64_t)hh * head_dim : q + tok * q_ts + (int64_t)hh * head_dim;
+    st4(dst + da, oa);
+    st4(dst + db, ob);
+    if (is_k && slot >= 0) {
+      uint16_t* kc = key_cache + slot * row + (int64_t)hh * head_dim;
+      st4(kc + da, oa);
+      st4(kc + db, ob);
+    }
+  }
+  // pass-through dims of q and k (rot_dim < head_dim), then v: plain T(sum) copies, 4 columns each
+  const int pass4 = (head_dim - rot_dim) / 4;
+  for (int i = tid; i < n_rot_heads * pass4; i += 256) {
+    const int h = i / pass4, d = rot_dim + 4 * (i % pass4);
+    const bool is_k = h >= n_heads;
+    const int hh = is_k ? h - n_heads : h;
+    float x[4];
+    ld4((int64_t)h * head_dim + d, x);
+    st4((is_k ? k + tok * k_ts : q + tok * q_ts) + (int64_t)hh * head_dim + d, x);
+    if (is_k && slot >= 0) st4(key_cache + slot * row + (int64_t)hh * head_dim + d, x);
+  }
+  const int64_t v_col0 = (int64_t)n_rot_heads * head_dim;
+  for (int i = tid; i < row / 4; i += 256) {
+    float x[4];
+    ld4(v_col0 + 4 * i, x);
+    st4(v + tok * v_ts + 4 * i, x);
+    if (slot >= 0) st4(value_cache + slot * row + 4 * i, x);
   }
 }
 
@@ -236,6 +344,47 @@ SLM_API int slm_rope_kv_append(void* q, int64_t q_token_stride, void* k, int64_t
     if (cos_sin_is_f32) SLM_ROPE(f16_tag, float); else SLM_ROPE(f16_tag, uint16_t);
   }
 #undef SLM_ROPE
+  return hip_check_launch();
+}
+
+SLM_API int slm_rope_kv_append_splitk(const float* partials, int32_t n_splits, void* q,
+                                      int64_t q_token_stride, void* k, int64_t k_token_stride,
+                                      void* v, int64_t v_token_stride, const int32_t* positions,
+                                      const void* cos_sin, int32_t cos_sin_is_f32, int32_t rot_dim,
+                                      int32_t interleaved, const int32_t* slot_ids, void* key_cache,
+                                      void* value_cache, int64_t n_tokens, int32_t n_heads,
+                                      int32_t n_kv_heads, int32_t head_dim, int32_t dtype,
+                                      void* stream) {
+  if (n_tokens == 0) return SLM_OK;
+  if (!partials || n_splits < 1 || !q || !k || !v || !positions || !cos_sin || n_tokens < 0 ||
+      n_heads <= 0 || n_kv_heads <= 0 || head_dim <= 0)
+    return SLM_ERR_INVALID_ARG;
+  if (rot_dim <= 0 || rot_dim > head_dim) return SLM_ERR_INVALID_ARG;
+  if (slot_ids && (!key_cache || !value_cache)) return SLM_ERR_INVALID_ARG;
+  if (dtype != SLM_F16 && dtype != SLM_BF16) return SLM_ERR_UNSUPPORTED;
+  // 16-byte partial loads / 8-byte stores: 4-column units everywhere
+  if (rot_dim % 8 || head_dim % 4 || q_token_stride % 4 || k_token_stride % 4 || v_token_stride % 4)
+    return SLM_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(partials) & 15) || (reinterpret_cast<uintptr_t>(q) & 7) ||
+      (reinterpret_cast<uintptr_t>(k) & 7) || (reinterpret_cast<uintptr_t>(v) & 7) ||
+      (reinterpret_cast<uintptr_t>(key_cache) & 7) || (reinterpret_cast<uintptr_t>(value_cache) & 7))
+    return SLM_ERR_ALIGNMENT;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hip_clear_error();
+  const int64_t N = (int64_t)(n_heads + 2 * n_kv_heads) * head_dim;
+  const dim3 grid((unsigned)n_tokens), blk(256);
+#define SLM_ROPE_SK(TT, CST)                                                                     \
+  hipLaunchKernelGGL((rope_kv_append_splitk_kernel<TT, CST>), grid, blk, 0, st, partials, n_splits, \
+                     n_tokens * N, N, (uint16_t*)q, q_token_stride, (uint16_t*)k, k_token_stride, \
+                     (uint16_t*)v, v_token_stride, positions, (const CST*)cos_sin, rot_dim,       \
+                     interleaved, slot_ids, (uint16_t*)key_cache, (uint16_t*)value_cache, n_heads, \
+                     n_kv_heads, head_dim)
+  if (dtype == SLM_BF16) {
+    if (cos_sin_is_f32) SLM_ROPE_SK(bf16_tag, float); else SLM_ROPE_SK(bf16_tag, uint16_t);
+  } else {
+    if (cos_sin_is_f32) SLM_ROPE_SK(f16_tag, float); else SLM_ROPE_SK(f16_tag, uint16_t);
+  }
+#undef SLM_ROPE_SK
   return hip_check_launch();
 }
 

@@ -106,6 +106,7 @@ class LlamaDecodeStep:
         # run as ONE launch each, fused with the residual add + RMSNorm that follows
         self.custom_ar = custom_allreduce
         self.shape, self.pa, self.dtype, self.device = shape, pa, dtype, torch.device(device)
+        self.defer_splitk = os.environ.get("SLM_DEFER_SPLITK", "1") != "0"  # read once, at build time
         tp = pa.world_size
         assert shape.n_heads % tp == 0 and shape.intermediate % tp == 0 and shape.hidden % tp == 0
         self.n_heads = shape.n_heads // tp
@@ -254,13 +255,15 @@ class LlamaDecodeStep:
 
         kernels.rms_norm(normed, resid, self.layers[0]["in_norm"], s.rms_eps)
         for li, L in enumerate(self.layers):
-            qkv = L["qkv"].forward(normed, out=b["qkv"][:T])
+            # a split-K GEMM hands its fp32 slabs straight to its consumer (one launch and one
+            # activation round trip less): qkv -> the RoPE + append kernel (any world size: the qkv
+            # projection is column-parallel), o / down -> the RMSNorm (single rank)
+            qkv = L["qkv"].forward(normed, out=b["qkv"][:T], defer_splitk=self.defer_splitk)
             nq, nkv = self.n_heads * D, self.n_kv_heads * D
             q, k, v = qkv[:, :nq], qkv[:, nq:nq + nkv], qkv[:, nq + nkv:]
-            attn = self.attn.forward(q, k, v, positions, L["kv"], params, output=b["attn"][:T])
-            # single rank: a split-K GEMM hands its fp32 slabs straight to the RMSNorm (one launch
-            # and one activation round trip less per row-parallel linear)
-            defer = pa.world_size == 1 and os.environ.get("SLM_DEFER_SPLITK", "1") != "0"
+            attn = self.attn.forward(q, k, v, positions, L["kv"], params, output=b["attn"][:T],
+                                     qkv_partials=L["qkv"].deferred if self.defer_splitk else None)
+            defer = pa.world_size == 1 and self.defer_splitk
             delta = L["o"].forward(attn, out=o_buf, reduce=False, defer_splitk=defer)
             reduce_add_norm(0, delta, L["post_norm"], L["o"].deferred if defer else None)
             if L["gate_up"].paired:  # SiLU*mul in the GEMM epilogue

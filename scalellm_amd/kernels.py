@@ -489,10 +489,16 @@ def apply_rotary_pos_emb(query: torch.Tensor, key: torch.Tensor, positions: torc
                          value: Optional[torch.Tensor] = None,
                          slot_ids: Optional[torch.Tensor] = None,
                          key_cache: Optional[torch.Tensor] = None,
-                         value_cache: Optional[torch.Tensor] = None) -> None:
+                         value_cache: Optional[torch.Tensor] = None,
+                         partials: Optional["DeferredPartials"] = None) -> None:
     """kernel::apply_rotary_pos_emb (pos_embedding_kernels.cu:83-121), in place on query/key
     [n_tokens, n_heads, head_dim]; with value/slot_ids/caches given it also performs the KV
-    append that follows it in AttentionImpl::forward (attention.cpp:36-42) in the same launch."""
+    append that follows it in AttentionImpl::forward (attention.cpp:36-42) in the same launch.
+
+    partials (truthy): query / key / value are the three column slices of ONE fused-qkv GEMM
+    output that was NOT written -- gptq_gemm(..., defer_reduce=True) left fp32 split-K slabs
+    behind; the kernel sums them itself (same order and rounding as the reduce kernel: identical
+    bits, one launch less) and WRITES query (rotated), key (rotated) and value."""
     L = _lib.lib()
     _require_gpu(query, key, positions, cos_sin, value, slot_ids, key_cache, value_cache)
     if query.stride(-1) != 1 or key.stride(-1) != 1 or query.stride(1) != query.size(2) or \
@@ -525,6 +531,33 @@ def apply_rotary_pos_emb(query: torch.Tensor, key: torch.Tensor, positions: torc
                     tuple(t.shape[1:]) != tuple(key.shape[1:]):
                 raise SlmError("caches must be contiguous [n_slots, n_kv_heads, head_dim] of the "
                                "activation dtype")
+    if partials:
+        if not isinstance(partials, DeferredPartials):
+            raise SlmError("apply_rotary_pos_emb(partials=...) takes the handle gptq_gemm(defer_reduce=True) returned")
+        n_cols = (query.size(1) + 2 * key.size(1)) * query.size(2)
+        if partials.key != _dev_key(query.device) or partials.numel != query.size(0) * n_cols:
+            raise SlmError("apply_rotary_pos_emb(partials=...): the handle belongs to another device or shape")
+        if _deferred_gen.get(partials.key) != partials.generation:
+            raise SlmError("apply_rotary_pos_emb(partials=...): stale handle -- a later deferred GEMM "
+                           "on this device has overwritten the slabs")
+        if value is None or value.shape != key.shape or value.stride(-1) != 1 or \
+                value.stride(-2) != value.size(-1):
+            raise SlmError("partials: value must be the [n_tokens, n_kv_heads, head_dim] slice of the qkv buffer")
+        # the three slices must be [q | k | v] of one row-major [n_tokens, n_cols] buffer
+        es = query.element_size()
+        if not (query.stride(0) == key.stride(0) == value.stride(0) == n_cols and
+                key.data_ptr() == query.data_ptr() + query.size(1) * query.size(2) * es and
+                value.data_ptr() == key.data_ptr() + key.size(1) * key.size(2) * es):
+            raise SlmError("partials: query / key / value must be the [q | k | v] column slices of "
+                           "the fused qkv GEMM output")
+        check(L.slm_rope_kv_append_splitk(
+            partials.ptr, partials.splits, query.data_ptr(), query.stride(0), key.data_ptr(),
+            key.stride(0), value.data_ptr(), value.stride(0), positions.data_ptr(),
+            cos_sin.data_ptr(), is_f32, int(rotary_dim), 1 if interleaved else 0,
+            slot_ids.data_ptr() if append else None, key_cache.data_ptr() if append else None,
+            value_cache.data_ptr() if append else None, query.size(0), query.size(1), key.size(1),
+            query.size(2), _dtype_code(query), _stream()), "slm_rope_kv_append_splitk")
+        return
     check(L.slm_rope_kv_append(
         query.data_ptr(), query.stride(0), key.data_ptr(), key.stride(0),
         value.data_ptr() if append else None, value.stride(0) if append else 0,

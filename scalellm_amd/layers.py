@@ -70,6 +70,9 @@ class HipAttnHandler:
         self.alibi_slopes = alibi_slopes
         self.rotary_dim, self.cos_sin, self.interleaved = rotary_dim, cos_sin, interleaved
         self._pending = None
+        # fp32 split-K slabs of the fused qkv GEMM (kernels.DeferredPartials), consumed by the next
+        # append_kv_cache(): the RoPE + append kernel then also does the split-K reduction
+        self.qkv_partials = None
 
     @staticmethod
     def build_cos_sin(rotary_dim: int, max_position: int, inv_freq: torch.Tensor) -> torch.Tensor:
@@ -86,13 +89,16 @@ class HipAttnHandler:
 
     def append_kv_cache(self, kv_cache: KVCache, query, key, value, input_params: InputParameters):
         kc, vc = kv_cache.get_kv_cache()
+        partials, self.qkv_partials = self.qkv_partials, None
         if self._pending is not None:
             kernels.apply_rotary_pos_emb(query, key, self._pending, self.cos_sin, self.rotary_dim,
                                          self.interleaved, value=value,
                                          slot_ids=input_params.new_cache_slots, key_cache=kc,
-                                         value_cache=vc)
+                                         value_cache=vc, partials=partials)
             self._pending = None
         else:
+            if partials:
+                raise kernels.SlmError("deferred qkv partials need the rotary path (no RoPE configured)")
             kernels.set_kv_cache(input_params.new_cache_slots, key, value, kc, vc)
 
     def batch_decode(self, query, kv_cache: KVCache, input_params: InputParameters,
@@ -115,7 +121,12 @@ class Attention:
         self.handler, self.sliding_window = handler, sliding_window
 
     def forward(self, query, key, value, positions, kv_cache: KVCache,
-                input_params: InputParameters, output: Optional[torch.Tensor] = None):
+                input_params: InputParameters, output: Optional[torch.Tensor] = None,
+                qkv_partials=None):
+        """qkv_partials (truthy kernels.DeferredPartials): query / key / value are the column slices
+        of a fused qkv GEMM output that was left as split-K slabs (ColumnParallelQLinear.forward(
+        defer_splitk=True)); the RoPE + append kernel sums them."""
+        self.handler.qkv_partials = qkv_partials if qkv_partials else None
         T = query.size(0)
         q = query.view(T, self.n_heads, self.head_dim)
         k = key.view(T, self.n_kv_heads, self.head_dim)
@@ -194,6 +205,7 @@ class _QLinearBase:
             if out is None:
                 out = torch.empty(x2.size(0), self._packed.N // 2, dtype=x.dtype, device=x.device)
             kernels.gptq_gemm(x2, self._packed, out, bias, silu_mul=True)
+            self.deferred, self.deferred_splits = kernels.DeferredPartials(), 0
             return out
         if out is None:
             out = torch.empty(x2.size(0), self._packed.N, dtype=x.dtype, device=x.device)
@@ -222,10 +234,16 @@ class ColumnParallelQLinear(_QLinearBase):
         if self.paired and gather_output:
             raise ValueError("act_mul needs the sharded output (gather_output=False)")
 
-    def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None,
+                defer_splitk: bool = False) -> torch.Tensor:
+        """defer_splitk (no bias, no gather, not act_mul): a split-K GEMM leaves its fp32 slabs for
+        the consumer (self.deferred is truthy then and `out` is NOT written) -- the fused qkv
+        projection hands them to the RoPE + append kernel (Attention.forward(qkv_partials=...))."""
         if self._packed is None:
             self._repack()
-        y = self._gemm(x, self.bias if self.has_bias else None, out)
+        defer = defer_splitk and not self.has_bias and not self.paired and \
+            not (self.parallel_args.world_size > 1 and self.gather_output)
+        y = self._gemm(x, self.bias if self.has_bias else None, out, defer_splitk=defer)
         if self.parallel_args.world_size > 1 and self.gather_output:
             y = gather_from_model_parallel_region(y, self.parallel_args)
         return y
