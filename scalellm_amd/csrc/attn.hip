@@ -65,9 +65,15 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
   const int hgb = bid % p.nhgb;
   const int tok = bid / p.nhgb;
 
-  // token -> sequence: q_cu[b] <= tok < q_cu[b+1]
+  // token -> sequence: q_cu[b] <= tok < q_cu[b+1].  Pure decode batches (one query token per
+  // sequence: q_cu[i] == i) are recognised with two independent loads instead of log2(batch)
+  // dependent ones -- the binary search is ~0.4 us per step of start-up latency in front of every
+  // workgroup's stream, which is what small batches are made of.
   int b;
-  {
+  const int tq0 = p.q_cu[min(tok, p.batch)], tq1 = p.q_cu[min(tok + 1, p.batch)];
+  if (tok < p.batch && tq0 == tok && tq1 == tok + 1) {
+    b = tok;
+  } else {
     int lo_b = 0, hi_b = p.batch;
     while (lo_b < hi_b) {
       const int mid = (lo_b + hi_b) >> 1;
@@ -388,11 +394,16 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const AttnKParams p, 
   __shared__ float wsm[4][COMBINE_MAX_SPLITS];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  const int64_t item = (int64_t)blockIdx.x * 4 + wv;
-  if (item >= (int64_t)p.n_tokens * p.n_heads) return;
+  // No early exit in front of the loads: out-of-range waves and graph-padding rows (past
+  // q_cu_lens[batch]: no kernel of the call wrote their partials) run on clamped / unwritten but
+  // in-bounds data and only skip the final store, so the q_cu lookup overlaps the partial loads
+  // instead of adding a round trip in front of them.
+  const int64_t n_items = (int64_t)p.n_tokens * p.n_heads;
+  const int64_t item_raw = (int64_t)blockIdx.x * 4 + wv;
+  bool valid = item_raw < n_items;
+  const int64_t item = valid ? item_raw : n_items - 1;
   const int tok = (int)(item / p.n_heads), head = (int)(item % p.n_heads);
-  // graph-padding rows past q_cu_lens[batch]: no kernel of the call wrote their partials
-  if (tok >= p.q_cu[p.batch]) return;
+  const int q_end = p.q_cu[p.batch];
   if (p.rows_hi != 0x7fffffff || p.rows_lo != 0) {
     // mixed call: only the rows the token-major kernel produced are combined
     int lo_b = 0, hi_b = p.batch;
@@ -468,7 +479,7 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const AttnKParams p, 
     acc.z += __shfl_xor(acc.z, d, 64);
     acc.w += __shfl_xor(acc.w, d, 64);
   }
-  if (phase == 0 && actd) {
+  if (valid && tok < q_end && phase == 0 && actd) {
     const float inv = L > 0.f ? 1.0f / L : 0.f;
     u32x2 r;
     r.x = pack2<T>(acc.x * inv, acc.y * inv);
