@@ -169,13 +169,33 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
   // (verify) form is at its 256-VGPR cap and spills with the 8 extra registers (335 -> 401 us), so
   // it looks the slots up right before its loads.
   constexpr bool AHEAD = NW > 1;
+  // One-wave form: the block-table slice of the workgroup's KV range is staged in LDS once (one
+  // coalesced read, as the decode kernel does), so the per-tile lookup is an LDS read (~100
+  // cycles) instead of an L2 round trip in front of every tile's K/V loads -- with one tile in
+  // flight per wave that round trip was ~20 % of the per-tile cycle.  Ranges longer than the
+  // staged window (TILE_TBL blocks) fall back to the global lookup.
+  constexpr int TILE_TBL = NW == 1 ? 2048 : 1;
+  __shared__ int tbl_lds[TILE_TBL];
+  bool tbl_staged = false;
+  const int blk_lo = wg_lo >> p.block_shift;
+  if constexpr (NW == 1) {
+    const int n_ent = wg_lo < wg_hi_s ? ((min(wg_hi_s, kv_len) - 1) >> p.block_shift) - blk_lo + 1 : 0;
+    tbl_staged = n_ent <= TILE_TBL;
+    if (tbl_staged) {
+      for (int i = tid; i < n_ent; i += nthreads) tbl_lds[i] = p.bt[bcu0 + blk_lo + i];
+      __syncthreads();
+    }
+  }
   int sreg[ITEMS];  // cache slots of the next tile_load
   auto slot_load = [&](int kt0) {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       const int r = (tid + nthreads * i) / NSLOT;
-      const int row = min(kt0 + r, kv_len - 1);  // clamp: masked below, must stay in bounds
-      sreg[i] = p.bt[bcu0 + (row >> p.block_shift)] + (row & p.block_mask);
+      // clamp: masked below, must stay in bounds (and inside the staged window)
+      const int row = min(kt0 + r, min(wg_hi_s, kv_len) - 1);
+      const int blk = row >> p.block_shift;
+      const int first = (NW == 1 && tbl_staged) ? tbl_lds[blk - blk_lo] : p.bt[bcu0 + blk];
+      sreg[i] = first + (row & p.block_mask);
     }
   };
   // K/V rows of the tile whose slots slot_load() fetched; then the slots of tile `kt_next`, so the
