@@ -120,15 +120,23 @@ def measure_attention_traffic_live(bs, kv_len, n_heads, n_kv_heads, block):
             r = subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
                                 sys.executable, tool], cwd="/tmp", env=env, capture_output=True, text=True,
                                timeout=300)
-            per = []
+            # one attention call = the stream kernel (token-major, or the MFMA tile form for wide GQA
+            # groups) + the split-KV combine kernel when the call is split: all of them count
+            total, n_main = 0.0, 0
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if "attn_token_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                            per.append(float(row["Counter_Value"]))
-            if r.returncode != 0 or not per:
+                        name = row["Kernel_Name"]
+                        if row["Counter_Name"] != counter:
+                            continue
+                        if "attn_token_kernel" in name or "attn_tile_kernel" in name:
+                            total += float(row["Counter_Value"])
+                            n_main += 1
+                        elif "attn_combine_kernel" in name:
+                            total += float(row["Counter_Value"])
+            if r.returncode != 0 or not n_main:
                 return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})"
-            vals[counter] = sum(per) / len(per)
+            vals[counter] = total / n_main
         except Exception as e:  # noqa: BLE001 -- the roofline line does not depend on the profiler
             return None, f"rocprofv3 --pmc {counter}: {type(e).__name__}"
         finally:
@@ -508,7 +516,11 @@ def main():
     traffic, traffic_src = (None, None)
     if rank == 0 and world == 1 and not args.no_traffic:
         traffic, traffic_src = measure_attention_traffic_live(bs, L, model.n_heads, model.n_kv_heads, B)
-    roofline = dict(kernel="attn_token_kernel (paged-attention decode)", bound="hbm",
+    # q_len = 1 runs on the MFMA tile kernel when the GQA group is wide (slm_hip's plan: group >= 8
+    # and >= 64 (sequence, KV head) pairs per launch), on the token-major stream kernel otherwise
+    on_tile = model.n_heads // model.n_kv_heads >= 8 and bs * model.n_kv_heads >= 64
+    roofline = dict(kernel="attn_tile_kernel (paged-attention decode, MFMA tile form)" if on_tile
+                    else "attn_token_kernel (paged-attention decode)", bound="hbm",
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=nbytes, avg_launch_us=round(avg_us, 2),

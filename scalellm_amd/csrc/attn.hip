@@ -497,6 +497,21 @@ struct AttnPlan {
   size_t lds_bytes;
 };
 
+// q_len = 1 sequences on the MFMA tile kernel?  With a wide GQA group the token kernel's VALU work
+// per KV byte (one dot-product / P.V chain per query head) is what bounds it -- G = 8: 4.4-5.3 TB/s
+// -- while the tile kernel's cost per KV byte does not depend on how many of its 32 query rows are
+// real: measured at G = 8, bs = 128, 4 k context: 1 KV head (the 70B TP = 8 rank) 61.2 -> 45.8 us,
+// 8 KV heads (70B TP = 1) 487 -> 370 us, 4.4 -> 5.8 TB/s.  At G = 4 (Llama-3-8B) the token kernel's
+// 6.9 TB/s stays ahead.  SLM_ATTN_TILE_DECODE: minimum group size (default 8), 0 = never.
+static bool decode_on_tile(const slm_attn_args* a) {
+  const int G = a->n_heads / a->n_kv_heads;
+  const int g_min = tune_get(TUNE_ATTN_TILE_DECODE, 8);
+  // small launches stay on the token kernel: with few (sequence, KV head) pairs the tile kernel's
+  // per-tile round trip dominates (8 pairs: 22 vs 13 us; 128 pairs: 48 vs 62 us; 256: 86 vs 128 us)
+  return g_min > 0 && G >= g_min && G <= 32 && a->num_splits <= 0 && attn_tile_supported(a->head_dim) &&
+         tune_get(TUNE_ATTN_TILE, 1) != 0 && (int64_t)a->batch_size * a->n_kv_heads >= 64;
+}
+
 static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
   if (!a) return SLM_ERR_INVALID_ARG;
   if (a->n_heads <= 0 || a->n_kv_heads <= 0 || a->n_heads % a->n_kv_heads) return SLM_ERR_INVALID_ARG;
@@ -551,7 +566,7 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
   // chunked prefill: its workgroups (one per 32 / 128 query rows per KV head) are too few to hide
   // HBM latency, so the KV range is split for it too (same partial format, same combine pass).
   // The count is shared by every kernel of the call.  Plain prefill (kv ~ q) is never split.
-  if (a->max_q_len > 1 && forced_splits <= 0 && attn_tile_supported(D) &&
+  if ((a->max_q_len > 1 || decode_on_tile(a)) && forced_splits <= 0 && attn_tile_supported(D) &&
       tune_get(TUNE_ATTN_TILE, 1) != 0 && a->max_kv_len >= 4 * (int64_t)a->max_q_len) {
     const int64_t rows_max = (int64_t)a->max_q_len * G;
     const int64_t nw_t = rows_max <= 32 ? 1 : rows_max <= 64 ? 2 : 4;
@@ -569,6 +584,8 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
       if (want > 16) want = 16;
     }
     if (want > n_splits) n_splits = (int)want;
+    // pure decode on the tile kernel: the token kernel does not run, its split count does not apply
+    if (a->max_q_len <= 1) n_splits = (int)(want > 0 ? want : 1);
   }
   if (n_splits > COMBINE_MAX_SPLITS) n_splits = COMBINE_MAX_SPLITS;
   pl->n_splits = n_splits;
@@ -700,37 +717,41 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
     kp.ml_part = kp.o_part + (size_t)a->n_tokens * a->n_heads * pl.n_splits * a->head_dim;
   }
   bool tile_used = false;
-  if (a->max_q_len > 1 && a->num_splits <= 0 && attn_tile_supported(kp.head_dim) &&
+  const bool dec_tile = decode_on_tile(a);
+  const int first_tile_rows = dec_tile ? kp.group : kp.group + 1;  // smallest row count on the tile kernel
+  if ((a->max_q_len > 1 || dec_tile) && a->num_splits <= 0 && attn_tile_supported(kp.head_dim) &&
       tune_get(TUNE_ATTN_TILE, 1) != 0) {
     hip_clear_error();
     const int64_t max_rows = (int64_t)a->max_q_len * kp.group;
     AttnKParams tk = kp;
-    if (kp.group + 1 < 33) {  // (group >= 32: every multi-row sequence already has > 32 rows)
-      tk.rows_lo = kp.group + 1;
+    if (first_tile_rows < 33) {  // (group >= 32: every multi-row sequence already has > 32 rows)
+      tk.rows_lo = first_tile_rows;
       tk.rows_hi = 33;
       rc = launch_attn_tile(tk, a->dtype, max_rows < 32 ? max_rows : 32, st);
       if (rc != SLM_OK) return rc;
     }
     if (max_rows > 32) {
       // rows <= group (q_len = 1) stay with the token-major kernel also when group > 32 (MQA)
-      tk.rows_lo = kp.group + 1 > 33 ? kp.group + 1 : 33;
+      tk.rows_lo = first_tile_rows > 33 ? first_tile_rows : 33;
       tk.rows_hi = 0x7fffffff;
       rc = launch_attn_tile(tk, a->dtype, max_rows, st);
       if (rc != SLM_OK) return rc;
     }
     // the token-major kernel keeps the q_len = 1 sequences
-    kp.rows_hi = kp.group + 1;
+    kp.rows_hi = first_tile_rows;
     tile_used = true;
   }
   hip_clear_error();
   const int64_t grid = (int64_t)a->n_tokens * pl.nhgb * pl.n_chunks * pl.n_splits;
   if (grid <= 0 || grid > 0x7fffffffLL) return SLM_ERR_INVALID_ARG;
-  if (a->dtype == SLM_BF16)
-    dispatch_lpr<bf16_tag>(kp, pl, grid, st);
-  else
-    dispatch_lpr<f16_tag>(kp, pl, grid, st);
-  rc = hip_check_launch();
-  if (rc != SLM_OK) return rc;
+  if (!(tile_used && dec_tile)) {  // (every sequence has >= group rows: nothing left for it then)
+    if (a->dtype == SLM_BF16)
+      dispatch_lpr<bf16_tag>(kp, pl, grid, st);
+    else
+      dispatch_lpr<f16_tag>(kp, pl, grid, st);
+    rc = hip_check_launch();
+    if (rc != SLM_OK) return rc;
+  }
   if (pl.n_splits > 1) {
     const int64_t items = (int64_t)a->n_tokens * a->n_heads;
     const dim3 g((unsigned)((items + 3) / 4)), blk(256);
