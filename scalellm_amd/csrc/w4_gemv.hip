@@ -283,6 +283,10 @@ void launch_gemv(const GemmKParams& kp, int dtype, int ng, hipStream_t st) {
   const int64_t tiles = kp.N / 32;
   int ks = 8;
   while (ks > 1 && (gp.n64 / ks < 4 || tiles * ks / 8 > 2048)) ks >>= 1;
+  // wide layers: about one workgroup per CU (more column tiles per workgroup, fewer K slices):
+  // every workgroup stages the activation vector, so 896 of them cost more than they hide --
+  // gate_up 4096 x 28672 at M = 1: 8 slices 19.6 us, 4 slices 16.7, 2 slices 15.5, 1 slice 22.3
+  while (ks > 2 && tiles * ks / 8 > 320) ks >>= 1;
   const int forced_ks = tune_get(TUNE_W4_GEMV_KS, 0);
   if (forced_ks == 1 || forced_ks == 2 || forced_ks == 4 || forced_ks == 8) ks = forced_ks;
   gp.silu = kp.silu;
