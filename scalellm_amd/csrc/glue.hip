@@ -16,8 +16,11 @@ namespace slm {
 
 __device__ __forceinline__ float wave_sum64(float v) { return group_sum<64>(v); }
 
-// one workgroup (256 threads) per token; dim % 8 == 0
-template <typename T>
+// one workgroup (256 threads) per token; dim % 8 == 0; NV = vectors of 8 columns per thread
+// (ceil(dim / 2048) rounded up to 1, 2, 4, 8).  Every load is unconditional (vector index clamped,
+// contribution masked): a load inside `if (vi < nvec)` makes hipcc wait for it at the join, one
+// memory round trip per unrolled iteration.
+template <typename T, int NV>
 __global__ void __launch_bounds__(256) rms_norm_kernel(uint16_t* __restrict__ out,
                                                        const uint16_t* __restrict__ x,
                                                        const uint16_t* __restrict__ weight,
@@ -28,37 +31,45 @@ __global__ void __launch_bounds__(256) rms_norm_kernel(uint16_t* __restrict__ ou
   const int64_t tok = blockIdx.x;
   const int tid = threadIdx.x;
   const int64_t nvec = dim / 8;
-  constexpr int MAXV = 8;  // up to 8 x 8 x 256 = 16384 columns
-  float v[MAXV][8];
+  float v[NV][8];
+  u32x4 wv[NV];
   float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int64_t vi = tid + 256 * i;
-    if (vi < nvec) {
-      u32x4 a;
-      if (part) {  // x = T(sum of the split-K partial slabs): what the reduce kernel would have left
-        const f32x4 s0 = splitk_sum4(part + tok * dim + vi * 8, slab, n_splits);
-        const f32x4 s1 = splitk_sum4(part + tok * dim + vi * 8 + 4, slab, n_splits);
-        a.x = pack2<T>(s0.x, s0.y); a.y = pack2<T>(s0.z, s0.w);
-        a.z = pack2<T>(s1.x, s1.y); a.w = pack2<T>(s1.z, s1.w);
-      } else {
-        a = *reinterpret_cast<const u32x4*>(x + tok * dim + vi * 8);
-      }
-      float f[8] = {lo_f32<T>(a.x), hi_f32<T>(a.x), lo_f32<T>(a.y), hi_f32<T>(a.y),
-                    lo_f32<T>(a.z), hi_f32<T>(a.z), lo_f32<T>(a.w), hi_f32<T>(a.w)};
-      if (residual) {  // x = input + residual (fp32), residual = T(x): normalization.h:42-52
-        const u32x4 r = *reinterpret_cast<const u32x4*>(residual + tok * dim + vi * 8);
-        f[0] += lo_f32<T>(r.x); f[1] += hi_f32<T>(r.x); f[2] += lo_f32<T>(r.y); f[3] += hi_f32<T>(r.y);
-        f[4] += lo_f32<T>(r.z); f[5] += hi_f32<T>(r.z); f[6] += lo_f32<T>(r.w); f[7] += hi_f32<T>(r.w);
-        u32x4 w;
-        w.x = pack2<T>(f[0], f[1]); w.y = pack2<T>(f[2], f[3]);
-        w.z = pack2<T>(f[4], f[5]); w.w = pack2<T>(f[6], f[7]);
-        *reinterpret_cast<u32x4*>(residual + tok * dim + vi * 8) = w;
-      }
+  for (int i = 0; i < NV; ++i) {  // the norm weights do not depend on anything: issue them first
+    const int64_t vic = min((int64_t)tid + 256 * i, nvec - 1);
+    wv[i] = *reinterpret_cast<const u32x4*>(weight + vic * 8);
+  }
+  u32x4 a[NV], r[NV];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[i][j] = f[j];
-      ss = rms_sumsq8(f, ss);
+  for (int i = 0; i < NV; ++i) {
+    const int64_t vic = min((int64_t)tid + 256 * i, nvec - 1);
+    if (part) {  // x = T(sum of the split-K partial slabs): what the reduce kernel would have left
+      const f32x4 s0 = splitk_sum4(part + tok * dim + vic * 8, slab, n_splits);
+      const f32x4 s1 = splitk_sum4(part + tok * dim + vic * 8 + 4, slab, n_splits);
+      a[i].x = pack2<T>(s0.x, s0.y); a[i].y = pack2<T>(s0.z, s0.w);
+      a[i].z = pack2<T>(s1.x, s1.y); a[i].w = pack2<T>(s1.z, s1.w);
+    } else {
+      a[i] = *reinterpret_cast<const u32x4*>(x + tok * dim + vic * 8);
     }
+    r[i] = residual ? *reinterpret_cast<const u32x4*>(residual + tok * dim + vic * 8) : u32x4{0u, 0u, 0u, 0u};
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int64_t vi = tid + 256 * i;
+    const bool valid = vi < nvec;
+    float f[8] = {lo_f32<T>(a[i].x), hi_f32<T>(a[i].x), lo_f32<T>(a[i].y), hi_f32<T>(a[i].y),
+                  lo_f32<T>(a[i].z), hi_f32<T>(a[i].z), lo_f32<T>(a[i].w), hi_f32<T>(a[i].w)};
+    if (residual) {  // x = input + residual (fp32), residual = T(x): normalization.h:42-52
+      f[0] += lo_f32<T>(r[i].x); f[1] += hi_f32<T>(r[i].x); f[2] += lo_f32<T>(r[i].y); f[3] += hi_f32<T>(r[i].y);
+      f[4] += lo_f32<T>(r[i].z); f[5] += hi_f32<T>(r[i].z); f[6] += lo_f32<T>(r[i].w); f[7] += hi_f32<T>(r[i].w);
+      u32x4 w;
+      w.x = pack2<T>(f[0], f[1]); w.y = pack2<T>(f[2], f[3]);
+      w.z = pack2<T>(f[4], f[5]); w.w = pack2<T>(f[6], f[7]);
+      if (valid) *reinterpret_cast<u32x4*>(residual + tok * dim + vi * 8) = w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[i][j] = f[j];
+    if (valid) ss = rms_sumsq8(f, ss);
   }
   ss = wave_sum64(ss);
   if ((tid & 63) == 0) red[tid >> 6] = ss;
@@ -66,12 +77,11 @@ __global__ void __launch_bounds__(256) rms_norm_kernel(uint16_t* __restrict__ ou
   const float tot = red[0] + red[1] + red[2] + red[3];
   const float rs = rsqrtf(tot / (float)dim + eps);
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int64_t vi = tid + 256 * i;
     if (vi < nvec) {
-      const u32x4 wv = *reinterpret_cast<const u32x4*>(weight + vi * 8);
-      const u32x4 r = rms_apply8<T>(v[i], rs, wv);
-      *reinterpret_cast<u32x4*>(out + tok * dim + vi * 8) = r;
+      const u32x4 o = rms_apply8<T>(v[i], rs, wv[i]);
+      *reinterpret_cast<u32x4*>(out + tok * dim + vi * 8) = o;
     }
   }
 }
@@ -290,16 +300,21 @@ static int rms_norm_launch(void* out, const void* x, const float* part, int32_t 
   hip_clear_error();
   const dim3 grid((unsigned)n_tokens), blk(256);
   const int64_t slab = n_tokens * dim;
-  if (dtype == SLM_BF16)
-    hipLaunchKernelGGL(rms_norm_kernel<bf16_tag>, grid, blk, 0, st, (uint16_t*)out,
-                       (const uint16_t*)x, (const uint16_t*)weight, (uint16_t*)residual, dim, eps,
-                       part, (int)n_splits, slab);
-  else if (dtype == SLM_F16)
-    hipLaunchKernelGGL(rms_norm_kernel<f16_tag>, grid, blk, 0, st, (uint16_t*)out,
-                       (const uint16_t*)x, (const uint16_t*)weight, (uint16_t*)residual, dim, eps,
-                       part, (int)n_splits, slab);
-  else
-    return SLM_ERR_UNSUPPORTED;
+  const int64_t per_thread = (dim / 8 + 255) / 256;
+#define SLM_NORM(TT, NVV)                                                                       \
+  hipLaunchKernelGGL((rms_norm_kernel<TT, NVV>), grid, blk, 0, st, (uint16_t*)out,              \
+                     (const uint16_t*)x, (const uint16_t*)weight, (uint16_t*)residual, dim, eps, \
+                     part, (int)n_splits, slab)
+#define SLM_NORM_NV(TT)                                                                         \
+  do {                                                                                          \
+    if (per_thread <= 1) SLM_NORM(TT, 1); else if (per_thread <= 2) SLM_NORM(TT, 2);            \
+    else if (per_thread <= 4) SLM_NORM(TT, 4); else SLM_NORM(TT, 8);                            \
+  } while (0)
+  if (dtype == SLM_BF16) SLM_NORM_NV(bf16_tag);
+  else if (dtype == SLM_F16) SLM_NORM_NV(f16_tag);
+  else return SLM_ERR_UNSUPPORTED;
+#undef SLM_NORM_NV
+#undef SLM_NORM
   return hip_check_launch();
 }
 
