@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <thread>
 
+#include "slm_attn_handler_hip.h"
 #include "slm_qlinear_hip.h"
 #include "slm_torch_shim.h"
 
@@ -100,6 +101,65 @@ PYBIND11_MODULE(_slm_shim, m) {
               make_args(quant_method, bits, group_size, desc_act, is_sym, zero_point),
               slm::ParallelArgs(rank, world_size, nullptr),
               torch::dtype(dtype).device(torch::Device(torch::kCUDA, device_index)));
+        });
+  // the attention layer boundary: KVCache / InputParameters / AttentionHandler / AttentionImpl
+  // (memory/kv_cache.h, models/parameters.h, layers/attention/{handler,attention}.h)
+  py::class_<slm::KVCache>(m, "KVCache")
+      .def(py::init([](int64_t n_blocks, int64_t block_size, int64_t n_kv_heads, int64_t head_dim,
+                       torch::ScalarType dtype, int device_index) {
+        return slm::KVCache(n_blocks, block_size, n_kv_heads, head_dim,
+                            torch::dtype(dtype).device(torch::Device(torch::kCUDA, device_index)));
+      }))
+      .def(py::init<>())
+      .def("empty", &slm::KVCache::empty)
+      .def("block_size", &slm::KVCache::block_size)
+      .def("get_kv_cache", &slm::KVCache::get_kv_cache)
+      .def("set_kv_cache", &slm::KVCache::set_kv_cache);
+  py::class_<slm::InputParameters>(m, "InputParameters")
+      .def(py::init<>())
+      .def_readwrite("num_sequences", &slm::InputParameters::num_sequences)
+      .def_readwrite("q_cu_seq_lens", &slm::InputParameters::q_cu_seq_lens)
+      .def_readwrite("kv_cu_seq_lens", &slm::InputParameters::kv_cu_seq_lens)
+      .def_readwrite("kv_max_seq_len", &slm::InputParameters::kv_max_seq_len)
+      .def_readwrite("q_max_seq_len", &slm::InputParameters::q_max_seq_len)
+      .def_readwrite("new_cache_slots", &slm::InputParameters::new_cache_slots)
+      .def_readwrite("block_tables", &slm::InputParameters::block_tables)
+      .def_readwrite("cu_block_lens", &slm::InputParameters::cu_block_lens);
+  py::class_<slm::HipAttnHandler>(m, "HipAttnHandler")
+      .def(py::init([](float sm_scale, float logits_soft_cap, int64_t rotary_dim, int64_t max_position,
+                       torch::Tensor inv_freq, bool interleaved, int device_index) {
+        return std::make_unique<slm::HipAttnHandler>(
+            sm_scale, logits_soft_cap, rotary_dim, max_position, std::move(inv_freq), interleaved,
+            torch::TensorOptions().device(torch::Device(torch::kCUDA, device_index)));
+      }))
+      .def(py::init([](float sm_scale, float logits_soft_cap, std::optional<torch::Tensor> alibi_slopes) {
+        return std::make_unique<slm::HipAttnHandler>(sm_scale, logits_soft_cap, std::move(alibi_slopes));
+      }))
+      .def("reserve", &slm::HipAttnHandler::reserve)
+      .def("get_estimate_workspace_size", &slm::HipAttnHandler::get_estimate_workspace_size)
+      .def("set_workspace", &slm::HipAttnHandler::set_workspace);
+  // AttentionImpl::forward through the virtual AttentionHandler interface
+  m.def("attention_forward",
+        [](slm::HipAttnHandler& handler, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim,
+           int32_t sliding_window, const torch::Tensor& query, const torch::Tensor& key,
+           const torch::Tensor& value, const torch::Tensor& positions, slm::KVCache& kv_cache,
+           const slm::InputParameters& params) {
+          slm::AttentionImpl attn(n_heads, n_kv_heads, head_dim, &handler, sliding_window);
+          return attn.forward(query, key, value, positions, kv_cache, params);
+        });
+  // the first two steps of AttentionImpl::forward alone (what a profiling run with an empty cache
+  // exercises): apply_pos_emb + append_kv_cache through the virtual interface
+  m.def("handler_pos_emb_and_append",
+        [](slm::HipAttnHandler& handler, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim,
+           torch::Tensor query, torch::Tensor key, const torch::Tensor& value,
+           const torch::Tensor& positions, slm::KVCache& kv_cache, const slm::InputParameters& params) {
+          slm::AttentionHandler& h = handler;
+          const int64_t T = query.size(0);
+          auto q = query.view({T, n_heads, head_dim});
+          auto k = key.view({T, n_kv_heads, head_dim});
+          auto v = value.view({T, n_kv_heads, head_dim});
+          std::tie(q, k) = h.apply_pos_emb(q, k, positions);
+          h.append_kv_cache(kv_cache, k, v, params);
         });
   py::class_<slm::W4Linear>(m, "W4Linear")
       .def(py::init<const std::string&, const torch::Tensor&, const torch::Tensor&,

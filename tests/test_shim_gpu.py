@@ -243,3 +243,111 @@ def test_cpp_parallel_qlinear_fused_load_and_argument_checks(shim):
         mk(K, 256, False, False, "gptq", 8, gs, False, True, False, 0, 1, torch.bfloat16, 0)
     with pytest.raises(RuntimeError, match="not divisible"):
         mk(K, 250, False, False, "awq", 4, gs, False, False, True, 0, 4, torch.bfloat16, 0)
+
+
+# ------------------------------------------------------------------ C++ AttentionHandler / AttentionImpl
+@pytest.mark.parametrize("mode", ["rope", "rope_interleaved_partial", "alibi"])
+def test_cpp_attention_impl_prefill_then_decode_matches_python_layer_and_oracle(shim, mode):
+    """slm::AttentionImpl::forward over slm::HipAttnHandler (compiled C++, the reference's
+    AttentionHandler interface: apply_pos_emb -> append_kv_cache -> batch_decode with RoPE and the KV
+    append fused into one launch) against the Python mirror (scalellm_amd.layers.Attention) on a
+    prefill step followed by two decode steps: identical bits for the outputs and for both KV caches;
+    the last decode output also against the oracle (rope + append + paged attention on the CPU)."""
+    from scalellm_amd.layers import Attention, HipAttnHandler, InputParameters, KVCache
+    H, HKV, D, B, nblk = 8, 2, 64, 16, 12
+    dt = torch.bfloat16
+    rot = {"rope": D, "rope_interleaved_partial": 32, "alibi": 0}[mode]
+    inter = mode == "rope_interleaved_partial"
+    g = torch.Generator(device=DEV).manual_seed(3)
+    sm = D ** -0.5
+    if rot:
+        inv = 1.0 / (10000.0 ** (torch.arange(0, rot, 2, dtype=torch.float32) / rot))
+        hc = shim.HipAttnHandler(sm, 0.0, rot, 256, inv, inter, 0)
+        hp = HipAttnHandler(sm, rotary_dim=rot, interleaved=inter,
+                            cos_sin=HipAttnHandler.build_cos_sin(rot, 256, inv.to(DEV)))
+        alibi = None
+    else:
+        alibi = (torch.rand(H, generator=torch.Generator().manual_seed(1)) / 64).to(DEV)
+        hc = shim.HipAttnHandler(sm, 0.0, alibi)
+        hp = HipAttnHandler(sm, alibi_slopes=alibi)
+    hc.reserve(64, H, D)
+    assert hc.get_estimate_workspace_size() > 0
+    hc.set_workspace(torch.empty(hc.get_estimate_workspace_size(), dtype=torch.uint8, device=DEV))
+    kvc = shim.KVCache(nblk, B, HKV, D, dt, 0)
+    kvp = KVCache(nblk, B, HKV, D, dt, DEV)
+    for t in kvc.get_kv_cache() + kvp.get_kv_cache():
+        t.zero_()
+    assert not kvc.empty() and kvc.block_size() == B and shim.KVCache().empty()
+    attn_p = Attention(H, HKV, D, hp)
+    # two sequences: prompt lengths 21 and 9; block tables = shuffled first-slot ids
+    blocks = [[5, 2, 9], [7, 1]]
+    lens = [21, 9]
+    table = torch.tensor([b * B for bl in blocks for b in bl], dtype=torch.int32, device=DEV)
+    cu_blk = torch.tensor([0, 3, 5], dtype=torch.int32, device=DEV)
+    outs = []
+    for step in range(3):
+        q_lens = lens if step == 0 else [1, 1]
+        kv_lens = [n + (0 if step == 0 else step) for n in lens]
+        pos = torch.cat([torch.arange(kv - ql, kv) for ql, kv in zip(q_lens, kv_lens)]).to(torch.int32).to(DEV)
+        slots = torch.tensor([blocks[s][int(p) // B] * B + int(p) % B
+                              for s, (ql, kv) in enumerate(zip(q_lens, kv_lens))
+                              for p in range(kv - ql, kv)], dtype=torch.int32, device=DEV)
+        T = sum(q_lens)
+        q = torch.randn(T, H * D, device=DEV, dtype=dt, generator=g)
+        k = torch.randn(T, HKV * D, device=DEV, dtype=dt, generator=g)
+        v = torch.randn(T, HKV * D, device=DEV, dtype=dt, generator=g)
+        cu = lambda xs: torch.tensor([0] + list(np.cumsum(xs)), dtype=torch.int32, device=DEV)  # noqa: E731
+        pc = shim.InputParameters()
+        pc.num_sequences = 2
+        pc.q_cu_seq_lens, pc.kv_cu_seq_lens = cu(q_lens), cu(kv_lens)
+        pc.q_max_seq_len, pc.kv_max_seq_len = max(q_lens), max(kv_lens)
+        pc.new_cache_slots, pc.block_tables, pc.cu_block_lens = slots, table, cu_blk
+        pp = InputParameters(q_cu_seq_lens=cu(q_lens), kv_cu_seq_lens=cu(kv_lens), new_cache_slots=slots,
+                             block_tables=table, cu_block_lens=cu_blk, q_max_seq_len=max(q_lens),
+                             kv_max_seq_len=max(kv_lens))
+        oc = shim.attention_forward(hc, H, HKV, D, -1, q.clone(), k.clone(), v.clone(), pos, kvc, pc)
+        op = attn_p.forward(q.clone(), k.clone(), v.clone(), pos, kvp, pp)
+        torch.cuda.synchronize()
+        assert torch.equal(oc, op), f"step {step}"
+        for a, b in zip(kvc.get_kv_cache(), kvp.get_kv_cache()):
+            assert torch.equal(a, b), f"cache after step {step}"
+        outs.append((q, k, v, pos, slots, q_lens, kv_lens, oc))
+    # oracle on the last decode step: rope(q), attention over the cache the C++ path built
+    q, k, v, pos, slots, q_lens, kv_lens, oc = outs[-1]
+    qf = q.float().cpu().numpy().reshape(-1, H, D)
+    if rot:
+        qf = oracle.rope(qf, pos.cpu().numpy(), inv.numpy(), rot, inter)
+        qf = helpers.bf16_bits_to_f32(helpers.f32_to_bf16_bits(qf))  # the kernel stores q rotated in bf16
+    kc, vc = (t.float().cpu().numpy() for t in kvc.get_kv_cache())
+    cu = lambda xs: np.concatenate([[0], np.cumsum(xs)]).astype(np.int32)  # noqa: E731
+    ref = oracle.paged_attn(qf, kc, vc, cu(q_lens), cu(kv_lens), table.cpu().numpy(), cu_blk.cpu().numpy(),
+                            B, sm, 0.0, -1, alibi.cpu().numpy() if alibi is not None else None)
+    np.testing.assert_allclose(oc.float().cpu().numpy().reshape(-1, H, D), ref, rtol=1e-2, atol=1e-2)
+
+
+def test_cpp_handler_profiling_run_with_empty_cache_only_rotates(shim):
+    """scale_attn_handler.cpp:76: with an empty KVCache (the memory-profiling forward) nothing is
+    appended; the HIP handler still has to rotate q / k."""
+    from scalellm_amd import kernels
+    from scalellm_amd.layers import HipAttnHandler
+    H, HKV, D = 4, 2, 64
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+    hc = shim.HipAttnHandler(D ** -0.5, 0.0, D, 128, inv, False, 0)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    q = torch.randn(5, H * D, device=DEV, dtype=torch.float16, generator=g)
+    k = torch.randn(5, HKV * D, device=DEV, dtype=torch.float16, generator=g)
+    v = torch.randn(5, HKV * D, device=DEV, dtype=torch.float16, generator=g)
+    pos = torch.arange(5, dtype=torch.int32, device=DEV)
+    q2, k2 = q.clone().view(5, H, D), k.clone().view(5, HKV, D)
+    kernels.apply_rotary_pos_emb(q2, k2, pos, HipAttnHandler.build_cos_sin(D, 128, inv.to(DEV)), D, False)
+    prm = shim.InputParameters()
+    prm.q_cu_seq_lens = prm.kv_cu_seq_lens = torch.tensor([0, 5], dtype=torch.int32, device=DEV)
+    prm.q_max_seq_len = prm.kv_max_seq_len = 5
+    empty = shim.KVCache()
+    qc, kc = q.clone(), k.clone()
+    # AttentionImpl::forward = apply_pos_emb + append_kv_cache + batch_decode; drive the first two
+    # through the module-level helper with a cache of zero blocks being rejected by batch_decode is
+    # not part of the profiling contract, so call the handler pieces the way AttentionImpl does
+    shim.handler_pos_emb_and_append(hc, H, HKV, D, qc, kc, v, pos, empty, prm)
+    torch.cuda.synchronize()
+    assert torch.equal(qc.view(5, H, D), q2) and torch.equal(kc.view(5, HKV, D), k2)
