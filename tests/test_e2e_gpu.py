@@ -81,12 +81,17 @@ def _llama_cases():
     from scalellm_amd.decode import LlamaShape
     shaped_8b = LlamaShape(hidden=4096, n_heads=32, n_kv_heads=8, head_dim=128, intermediate=14336,
                            n_layers=2, vocab=8192, max_position=1024)
+    # 8 query heads per KV head (the Llama-3-70B ratio) and 33 sequences = 66 (sequence, KV head)
+    # pairs: the decode steps of this case run their attention on the MFMA tile kernel
+    gqa8 = LlamaShape(hidden=256, n_heads=16, n_kv_heads=2, head_dim=64, intermediate=512,
+                      n_layers=2, vocab=1024, max_position=512)
     return {"tiny-awq": (LlamaShape.tiny(), "awq", 128, [37, 45, 5, 18]),
             "tiny-gptq-g64": (LlamaShape.tiny(), "gptq", 64, [37, 45, 5, 18]),
-            "8b-shaped-2-layers-awq": (shaped_8b, "awq", 128, [23, 45, 12])}
+            "8b-shaped-2-layers-awq": (shaped_8b, "awq", 128, [23, 45, 12]),
+            "tiny-gqa8-awq": (gqa8, "awq", 128, [9, 26] + [3 + (7 * i) % 11 for i in range(31)])}
 
 
-@pytest.mark.parametrize("name", ["tiny-awq", "tiny-gptq-g64", "8b-shaped-2-layers-awq"])
+@pytest.mark.parametrize("name", ["tiny-awq", "tiny-gptq-g64", "8b-shaped-2-layers-awq", "tiny-gqa8-awq"])
 def test_llama_prefill_then_decode_logits_match_oracle(name):
     from scalellm_amd.decode import LlamaDecodeStep
     shape, quant, gs, prompt_lens = _llama_cases()[name]
