@@ -105,6 +105,11 @@ def lib() -> C.CDLL:
         ("slm_w4_prepack", C.c_int,
          [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
           C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+        ("slm_w4_prepack_weights", C.c_int,
+         [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+        ("slm_w4_prepack_sz", C.c_int,
+         [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
+          C.c_void_p]),
         ("slm_w4a16_gemm_workspace_bytes", C.c_size_t, [C.POINTER(W4GemmArgs)]),
         ("slm_w4a16_gemm", C.c_int, [C.POINTER(W4GemmArgs), C.c_void_p]),
         ("slm_w4a16_gemm_deferred_splits", C.c_int32, [C.POINTER(W4GemmArgs)]),

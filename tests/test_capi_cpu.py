@@ -220,6 +220,48 @@ def test_deferred_splitk_reduce_host_side():
     assert L.slm_rms_norm_splitk(256, 256, 4, 256, None, 0, 4096, 1e-5, 1, None) == 0     # empty batch
 
 
+def test_round2_entry_points_validate_before_any_launch():
+    """SiLU*mul epilogue flag, paired prepack format and the split-K RoPE form: argument checks
+    that must hold without a GPU (every one returns before the first HIP call)."""
+    L = _lib.lib()
+    assert L.slm_tuning_clear(None) == 0
+    g = W4GemmArgs()
+    g.M, g.K, g.N, g.lda, g.ldc, g.group_size, g.dtype = 32, 4096, 28672, 4096, 14336, 128, 1
+    g.flags = _lib.SLM_W4_SILU_MUL
+    assert L.slm_w4a16_gemm_workspace_bytes(C.byref(g)) >= 0             # a valid plan
+    g.flags = _lib.SLM_W4_SILU_MUL | _lib.SLM_W4_DEFER_REDUCE            # cannot be combined
+    assert L.slm_w4a16_gemm(C.byref(g), None) == -1
+    g.flags = 64                                                          # unknown flag bit
+    assert L.slm_w4a16_gemm(C.byref(g), None) == -1
+    g.flags, g.N, g.ldc = _lib.SLM_W4_SILU_MUL, 96, 48                    # N % 64 != 0
+    assert L.slm_w4a16_gemm(C.byref(g), None) == -2
+    # prepack: PAIRED needs N % 64 == 0; unknown format bits are rejected
+    assert L.slm_w4_prepack_weights(_lib.SLM_W4_AWQ | _lib.SLM_W4_PAIRED, 256, None, 128, 96, 256, None) == -2
+    assert L.slm_w4_prepack_weights(_lib.SLM_W4_AWQ | 0x40, 256, None, 128, 128, 256, None) == -2
+    assert L.slm_w4_prepack_sz(_lib.SLM_W4_GPTQ | _lib.SLM_W4_PAIRED, None, 256, 128, 96, 128, 1, 256, None) == -2
+    # slm_rope_kv_append_splitk(partials, n_splits, q, q_ts, k, k_ts, v, v_ts, positions, cos_sin,
+    #                           cos_sin_is_f32, rot_dim, interleaved, slot_ids, kc, vc, T, H, HKV, D, dtype, stream)
+    ok = dict(partials=256, n_splits=4, q=512, q_ts=6144, k=1024, k_ts=6144, v=2048, v_ts=6144, pos=4096,
+              cs=8192, f32=1, rot=128, inter=0, slots=None, kc=None, vc=None, T=8, H=32, HKV=8, D=128, dt=1)
+
+    def call(**kw):
+        a = dict(ok, **kw)
+        return L.slm_rope_kv_append_splitk(a["partials"], a["n_splits"], a["q"], a["q_ts"], a["k"], a["k_ts"],
+                                           a["v"], a["v_ts"], a["pos"], a["cs"], a["f32"], a["rot"], a["inter"],
+                                           a["slots"], a["kc"], a["vc"], a["T"], a["H"], a["HKV"], a["D"],
+                                           a["dt"], None)
+    assert call(T=0) == 0                       # empty batch
+    assert call(partials=None) == -1
+    assert call(n_splits=0) == -1
+    assert call(cs=None) == -1                  # the split-K form needs the rotary table
+    assert call(slots=4096) == -1               # append without caches
+    assert call(rot=20) == -2                   # rot_dim % 8 (16-byte partial loads)
+    assert call(D=130, rot=128) == -2           # head_dim % 4
+    assert call(q_ts=6146) == -2
+    assert call(partials=264) == -5             # alignment
+    assert call(dt=7) == -2                     # unknown dtype code
+
+
 def test_python_mirror_fails_loudly_on_cpu_tensors():
     """No CPU / PyTorch fallback anywhere in the product path."""
     from scalellm_amd import kernels
