@@ -551,6 +551,27 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
     if (want > max_by_len) want = max_by_len;
     if (want < 1) want = 1;
     if (want > COMBINE_MAX_SPLITS) want = COMBINE_MAX_SPLITS;
+    {
+      // workgroup-count quantisation: 288 workgroups on 256 CUs take as long as 512 (bs = 96:
+      // 3 splits = 288 workgroups ran at 4.5 TB/s).  Look a few split counts further for one whose
+      // grid fills whole rounds of the CUs (>= 90 %), and take the best seen otherwise.
+      auto fill = [&](int64_t sp) {
+        const int64_t w = base * sp;
+        return (double)w / (double)(((w + target_wgs - 1) / target_wgs) * target_wgs);
+      };
+      int64_t s_max = want * 4 > want + 3 ? want * 4 : want + 3;
+      if (s_max > max_by_len) s_max = max_by_len;
+      if (s_max > COMBINE_MAX_SPLITS) s_max = COMBINE_MAX_SPLITS;
+      int64_t best = want;
+      double best_fill = fill(want);
+      for (int64_t sp = want + 1; sp <= s_max && best_fill < 0.9; ++sp) {
+        if (fill(sp) > best_fill + 0.02) {
+          best = sp;
+          best_fill = fill(sp);
+        }
+      }
+      want = best;
+    }
     n_splits = forced_splits > 0 ? forced_splits : (int)want;
     // tiny batches: if the grid is still short of one workgroup per CU, stop sharing a
     // workgroup between head groups (doubles / quadruples the workgroup count)
