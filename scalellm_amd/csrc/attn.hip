@@ -551,7 +551,7 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
     if (want > max_by_len) want = max_by_len;
     if (want < 1) want = 1;
     if (want > COMBINE_MAX_SPLITS) want = COMBINE_MAX_SPLITS;
-    {
+    if (a->max_q_len <= 1) {  // (pure decode: n_tokens IS the token kernel's row count)
       // workgroup-count quantisation: 288 workgroups on 256 CUs take as long as 512 (bs = 96:
       // 3 splits = 288 workgroups ran at 4.5 TB/s).  Look a few split counts further for one whose
       // grid fills whole rounds of the CUs (>= 90 %), and take the best seen otherwise.
