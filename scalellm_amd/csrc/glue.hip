@@ -212,7 +212,10 @@ __global__ void __launch_bounds__(256) rope_kv_append_splitk_kernel(
   };
   const int upr = half / 4;                  // rotary units per head
   const int n_rot_heads = n_heads + n_kv_heads;  // q heads, then k heads
-  for (int i = tid; i < n_rot_heads * upr; i += 256) {
+  // gridDim.y workgroups share a token: one 4 + 4-value unit per thread and pass, so the partial
+  // loads of a thread are one round trip, not one per loop iteration
+  const int tstep = 256 * gridDim.y, t0 = tid + 256 * blockIdx.y;
+  for (int i = t0; i < n_rot_heads * upr; i += tstep) {
     const int h = i / upr, u = i % upr;
     const bool is_k = h >= n_heads;
     const int hh = is_k ? h - n_heads : h;
@@ -245,7 +248,7 @@ __global__ void __launch_bounds__(256) rope_kv_append_splitk_kernel(
   }
   // pass-through dims of q and k (rot_dim < head_dim), then v: plain T(sum) copies, 4 columns each
   const int pass4 = (head_dim - rot_dim) / 4;
-  for (int i = tid; i < n_rot_heads * pass4; i += 256) {
+  for (int i = t0; i < n_rot_heads * pass4; i += tstep) {
     const int h = i / pass4, d = rot_dim + 4 * (i % pass4);
     const bool is_k = h >= n_heads;
     const int hh = is_k ? h - n_heads : h;
@@ -255,7 +258,7 @@ __global__ void __launch_bounds__(256) rope_kv_append_splitk_kernel(
     if (is_k && slot >= 0) st4(key_cache + slot * row + (int64_t)hh * head_dim + d, x);
   }
   const int64_t v_col0 = (int64_t)n_rot_heads * head_dim;
-  for (int i = tid; i < row / 4; i += 256) {
+  for (int i = t0; i < row / 4; i += tstep) {
     float x[4];
     ld4(v_col0 + 4 * i, x);
     st4(v + tok * v_ts + 4 * i, x);
@@ -387,7 +390,9 @@ SLM_API int slm_rope_kv_append_splitk(const float* partials, int32_t n_splits, v
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hip_clear_error();
   const int64_t N = (int64_t)(n_heads + 2 * n_kv_heads) * head_dim;
-  const dim3 grid((unsigned)n_tokens), blk(256);
+  const int64_t units = ((int64_t)(n_heads + n_kv_heads) * (rot_dim / 8) + (int64_t)n_kv_heads * head_dim / 4);
+  const unsigned gy = units > 768 ? 4u : units > 256 ? 2u : 1u;
+  const dim3 grid((unsigned)n_tokens, gy), blk(256);
 #define SLM_ROPE_SK(TT, CST)                                                                     \
   hipLaunchKernelGGL((rope_kv_append_splitk_kernel<TT, CST>), grid, blk, 0, st, partials, n_splits, \
                      n_tokens * N, N, (uint16_t*)q, q_token_stride, (uint16_t*)k, k_token_stride, \
