@@ -1,0 +1,126 @@
+"""Host mirror of the reference's ModelRunner (src/engine/model_runner.{h,cpp}): decode steps are
+captured ONCE per batch size into a hipGraph over shared static input buffers and replayed with the
+step's inputs copied in; anything a captured graph does not cover runs eagerly
+(model_runner.cpp:112-140).
+
+Same contract as the reference:
+  * one graph per batch size in `cuda_graph_batch_sizes`, each sequence contributing exactly
+    `num_decoding_tokens` query tokens (1 = plain decode, k + 1 = speculative verify);
+  * captured with `kv_max_seq_len = cuda_graph_max_seq_len` (model_runner.cpp:88-90): the launch
+    plans of the kernels are fixed at capture time from that bound, the ACTUAL lengths, slots and
+    block tables are read from the device buffers at replay -- which is why every kernel of
+    libslm_hip takes its lengths from device memory and treats `max_kv_len` as a hint only;
+  * replay when the batch size was captured, kv_max_seq_len <= the bound and every sequence has
+    num_decoding_tokens tokens; eager otherwise;
+  * the block table is copied into a buffer padded to the capture-time maximum
+    (model_runner.cpp:196-200).
+
+The model is anything with `forward(tokens, positions, params, **kw) -> Tensor` whose output lives
+in a static buffer (scalellm_amd.decode.LlamaDecodeStep returns views of its own buffers).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from .layers import InputParameters
+
+
+@dataclass
+class ModelRunnerOptions:
+    """ModelRunner::Options (model_runner.h:17-33)."""
+    block_size: int = 16
+    cuda_graph_max_seq_len: int = 2048
+    cuda_graph_batch_sizes: List[int] = field(default_factory=list)
+    num_decoding_tokens: int = 1
+
+
+class _Graph:
+    """ModelRunner::CudaGraph (model_runner.cpp:142-211)."""
+
+    def __init__(self, runner: "ModelRunner", batch_size: int):
+        self.batch_size = batch_size
+        self.n_tokens = batch_size * runner.options.num_decoding_tokens
+        r, n, b = runner, self.n_tokens, batch_size
+        self.tokens, self.positions = r.token_ids[:n], r.positions[:n]
+        self.params = InputParameters(
+            q_cu_seq_lens=r.q_cu_seq_lens[:b + 1], kv_cu_seq_lens=r.kv_cu_seq_lens[:b + 1],
+            new_cache_slots=r.new_cache_slots[:n], block_tables=r.block_tables,
+            cu_block_lens=r.cu_block_lens[:b + 1], q_max_seq_len=r.options.num_decoding_tokens,
+            kv_max_seq_len=r.options.cuda_graph_max_seq_len)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.output: Optional[torch.Tensor] = None
+
+    def capture(self, fn: Callable) -> None:
+        # warm up (workspaces grow here, not under capture), then capture on a side stream
+        torch.cuda.synchronize()
+        fn(self.tokens, self.positions, self.params)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.output = fn(self.tokens, self.positions, self.params)
+        torch.cuda.synchronize()
+
+    def replay(self, tokens, positions, params: InputParameters) -> torch.Tensor:
+        if tokens.numel() != self.n_tokens:
+            raise ValueError("num tokens mismatch")
+        if params.block_tables.numel() > self.params.block_tables.numel():
+            raise ValueError("block table larger than the captured maximum")
+        self.tokens.copy_(tokens, non_blocking=True)
+        self.positions.copy_(positions, non_blocking=True)
+        self.params.q_cu_seq_lens.copy_(params.q_cu_seq_lens, non_blocking=True)
+        self.params.kv_cu_seq_lens.copy_(params.kv_cu_seq_lens, non_blocking=True)
+        self.params.new_cache_slots.copy_(params.new_cache_slots, non_blocking=True)
+        self.params.block_tables[:params.block_tables.numel()].copy_(params.block_tables, non_blocking=True)
+        self.params.cu_block_lens.copy_(params.cu_block_lens, non_blocking=True)
+        self.graph.replay()
+        return self.output
+
+
+class ModelRunner:
+    def __init__(self, model, device, options: ModelRunnerOptions, **forward_kwargs):
+        self.model, self.device, self.options = model, torch.device(device), options
+        self.forward_kwargs = forward_kwargs
+        self.graphs: Dict[int, _Graph] = {}
+        self.num_graph_replayed = 0  # the reference's two counters (model_runner.cpp:14-21)
+        self.num_eager = 0
+        if options.cuda_graph_batch_sizes:
+            mb = max(options.cuda_graph_batch_sizes)
+            nd = options.num_decoding_tokens
+            i32 = dict(dtype=torch.int32, device=self.device)
+            self.max_batch_size = mb
+            self.token_ids = torch.zeros(nd * mb, **i32)
+            self.positions = torch.zeros(nd * mb, **i32)
+            self.q_cu_seq_lens = torch.arange(0, nd * mb + 1, nd, **i32)
+            self.kv_cu_seq_lens = torch.arange(0, nd * mb + 1, nd, **i32)
+            self.new_cache_slots = torch.zeros(nd * mb, **i32)
+            # round up, plus one block per sequence for speculative decoding (model_runner.cpp:56-61)
+            per_seq = (options.cuda_graph_max_seq_len + options.block_size - 1) // options.block_size + 1
+            self.block_tables = torch.zeros(mb * per_seq, **i32)
+            self.cu_block_lens = torch.zeros(mb + 1, **i32)
+
+    def _run(self, tokens, positions, params):
+        return self.model.forward(tokens, positions, params, **self.forward_kwargs)
+
+    def capture_cuda_graphs(self, batch_size: int) -> None:
+        if not self.options.cuda_graph_batch_sizes:
+            return
+        if batch_size > self.max_batch_size:
+            raise ValueError("batch size too big")
+        g = _Graph(self, batch_size)
+        g.capture(self._run)
+        self.graphs[batch_size] = g
+
+    def forward(self, tokens, positions, params: InputParameters, num_sequences: Optional[int] = None):
+        bs = int(params.q_cu_seq_lens.numel() - 1) if num_sequences is None else num_sequences
+        g = self.graphs.get(bs)
+        if g is not None:
+            nd = self.options.num_decoding_tokens
+            if (params.kv_max_seq_len <= self.options.cuda_graph_max_seq_len and
+                    params.q_max_seq_len == nd and tokens.numel() == bs * nd):
+                self.num_graph_replayed += 1
+                return g.replay(tokens, positions, params)
+        self.num_eager += 1
+        return self._run(tokens, positions, params)
