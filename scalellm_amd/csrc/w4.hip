@@ -598,8 +598,14 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   // small-M tiles use the post-scaled form (7 VALU per 8 weights instead of ~27)
   pl->post = tune_get(TUNE_W4_POST, a->M <= 64 ? 1 : 0) != 0 && mt <= 2;
   pl->lds_bytes = (size_t)2 * pc * bm * 256 + (pl->post ? (size_t)2 * pc * pl->ng * bm * sizeof(float) : 0);
-  if (pl->gemv) {  // K is split inside the workgroup: no partials, no reduce launch
-    pl->split_k = 1;
+  if (pl->gemv) {
+    // K is split inside the workgroup: no partials, no reduce launch.  Exception: when the caller
+    // defers the reduction to the consumer anyway (SLM_W4_DEFER_REDUCE: RMSNorm, RoPE + append)
+    // a narrow layer is ALSO split across workgroups so that its launch covers all the CUs --
+    // o_proj at M = 1 has 128 column tiles = 128 workgroups on 256 CUs, and a CU's load path
+    // (~14 B/clk) caps 128 of them at ~3.3 TB/s.
+    pl->split_k = gemv_global_splits(a->M, a->K, a->N,
+                                     (a->flags & SLM_W4_DEFER_REDUCE) && !a->bias && !a->perm);
     pl->chunks_per_split = n_chunks;
   }
   pl->part_bytes = pl->split_k > 1 ? (size_t)pl->split_k * a->M * a->N * sizeof(float) : 0;

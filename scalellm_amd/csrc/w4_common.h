@@ -157,6 +157,8 @@ constexpr int W4_KC = 128;  // K granularity of the plan (split-K units, LDS chu
 // dot2 GEMV for M <= 4 (w4_gemv.hip): no MFMA, activations resident in LDS, K split inside the workgroup
 bool gemv_supported(int64_t M, int64_t K, int64_t group_size);
 void launch_gemv(const GemmKParams& kp, int dtype, int ng, hipStream_t st);
+// K splits across workgroups (1 = none; > 1 only when the caller takes fp32 partial slabs)
+int gemv_global_splits(int64_t M, int64_t K, int64_t N, bool partials_ok);
 
 // lean weight-streaming kernel for M <= 32 (w4_small.hip): BM = 32, BN = 128, 256 threads
 void launch_gemm_small(const GemmKParams& kp, int dtype, int ng, int n_blocks, hipStream_t st);

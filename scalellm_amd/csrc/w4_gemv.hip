@@ -34,6 +34,9 @@ struct GemvParams {
   int gs_shift;  // log2(group size); 30 = per-channel
   int tw, ks;    // column tiles x K slices per workgroup (tw * ks = 8)
   int n64;       // K / 64
+  int splits;    // K splits across workgroups (> 1: fp32 partial slabs to `part`, c not written)
+  int n_wgs;     // workgroups per split
+  float* part;   // [splits][M][N]
   int silu;      // SLM_W4_SILU_MUL: tw is even, tiles (2j, 2j+1) = (gate, up), c is [M, N/2]
 };
 
@@ -58,11 +61,12 @@ __global__ void __launch_bounds__(512) w4a16_gemv_kernel(const GemvParams p) {
   // ---- this wave's column tile and K slice; its weight ring is issued FIRST so that the HBM
   // latency of the first chunks overlaps the activation staging below ----
   const int tw_i = wave % p.tw, ks_i = wave / p.tw;
-  int64_t nt = (int64_t)blockIdx.x * p.tw + tw_i;
+  const int split_id = (int)blockIdx.x / p.n_wgs, wg = (int)blockIdx.x % p.n_wgs;
+  int64_t nt = (int64_t)wg * p.tw + tw_i;
   const bool nvalid = nt < n_tiles;
   if (!nvalid) nt = n_tiles - 1;  // clamped duplicate work, never stored
-  const int per = (p.n64 + p.ks - 1) / p.ks;
-  const int c0 = ks_i * per;
+  const int per = (p.n64 + p.ks * p.splits - 1) / (p.ks * p.splits);
+  const int c0 = (split_id * p.ks + ks_i) * per;
   const int c1 = min(p.n64, c0 + per);
   const int nC = max(c1 - c0, 0);
   const int last = max(c1 - 1, 0);
@@ -230,6 +234,18 @@ __global__ void __launch_bounds__(512) w4a16_gemv_kernel(const GemvParams p) {
     }
     return;
   }
+  if (p.splits > 1) {  // this split's share of the sum, fp32, for the deferred consumer
+    if (ks_i == 0 && nvalid && lane < 32) {
+      const int64_t ncol = nt * 32 + lane;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        float s = 0.f;
+        for (int k = 0; k < p.ks; ++k) s += red[((k * p.tw + tw_i) * MT + m) * 32 + lane];
+        if (m < p.M) p.part[((int64_t)split_id * p.M + m) * p.N + ncol] = s;
+      }
+    }
+    return;
+  }
   if (ks_i == 0 && nvalid && lane < 32) {
     const int64_t ncol = nt * 32 + lane;
     float bv = 0.f;
@@ -248,7 +264,8 @@ static void launch_gemv_m(const GemvParams& gp, int n_wgs, size_t lds, hipStream
   // measured: keeping the (clamped, L2-hit) refills even when the slice fits the ring is FASTER on
   // the wide layers (gate_up M=1 17.5-19 us vs 23.4 us without them) -- the extra loads keep the
   // issue pattern the compiler's counted waits were built for; SLM_W4_GEMV_REFILL=0 disables them
-  const bool refill = (gp.n64 + gp.ks - 1) / gp.ks > GV_RING || tune_get(TUNE_W4_GEMV_REFILL, 1) != 0;
+  const bool refill = (gp.n64 + gp.ks * gp.splits - 1) / (gp.ks * gp.splits) > GV_RING ||
+                      tune_get(TUNE_W4_GEMV_REFILL, 1) != 0;
 #define SLM_GEMV(MTT)                                                                          \
   do {                                                                                         \
     auto kfn = refill ? w4a16_gemv_kernel<T, NGC, MTT, true> : w4a16_gemv_kernel<T, NGC, MTT, false>; \
@@ -256,7 +273,7 @@ static void launch_gemv_m(const GemvParams& gp, int n_wgs, size_t lds, hipStream
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
     }                                                                                          \
-    hipLaunchKernelGGL(kfn, dim3((unsigned)n_wgs), dim3(512), lds, st, gp);                    \
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(n_wgs * gp.splits)), dim3(512), lds, st, gp);      \
   } while (0)
   if (gp.M <= 1) SLM_GEMV(1);
   else if (gp.M <= 2) SLM_GEMV(2);
@@ -272,28 +289,50 @@ bool gemv_supported(int64_t M, int64_t K, int64_t group_size) {
   return lds <= 160 * 1024 && K % 64 == 0;  // (the < 4 GiB checks are in launch_gemv's caller)
 }
 
-void launch_gemv(const GemmKParams& kp, int dtype, int ng, hipStream_t st) {
-  GemvParams gp;
-  gp.a = kp.a; gp.wq = kp.wq; gp.sz = kp.sz; gp.bias = kp.bias; gp.c = kp.c;
-  gp.M = kp.M; gp.K = kp.K; gp.N = kp.N; gp.lda = kp.lda; gp.ldc = kp.ldc;
-  gp.gs_shift = kp.gs_shift;
-  gp.n64 = (int)(kp.K / 64);
+static void gemv_shape(int64_t K, int64_t N, bool silu, int& ks, int& tw, int& n_wgs) {
+  const int n64 = (int)(K / 64);
   // 8 waves per workgroup = tw column tiles x ks K-slices: enough workgroups to cover the CUs a
   // few times over, but at least 4 chunks (256 of K) per slice
-  const int64_t tiles = kp.N / 32;
-  int ks = 8;
-  while (ks > 1 && (gp.n64 / ks < 4 || tiles * ks / 8 > 2048)) ks >>= 1;
+  const int64_t tiles = N / 32;
+  ks = 8;
+  while (ks > 1 && (n64 / ks < 4 || tiles * ks / 8 > 2048)) ks >>= 1;
   // wide layers: about one workgroup per CU (more column tiles per workgroup, fewer K slices):
   // every workgroup stages the activation vector, so 896 of them cost more than they hide --
   // gate_up 4096 x 28672 at M = 1: 8 slices 19.6 us, 4 slices 16.7, 2 slices 15.5, 1 slice 22.3
   while (ks > 2 && tiles * ks / 8 > 320) ks >>= 1;
   const int forced_ks = tune_get(TUNE_W4_GEMV_KS, 0);
   if (forced_ks == 1 || forced_ks == 2 || forced_ks == 4 || forced_ks == 8) ks = forced_ks;
+  if (silu && ks == 8) ks = 4;  // a (gate, up) tile pair has to share the workgroup: tw >= 2
+  tw = 8 / ks;
+  n_wgs = (int)((tiles + tw - 1) / tw);
+}
+
+int gemv_global_splits(int64_t M, int64_t K, int64_t N, bool partials_ok) {
+  (void)M;
+  if (!partials_ok) return 1;
+  const int forced = tune_get(TUNE_W4_SPLITK, 0);
+  int ks, tw, n_wgs;
+  gemv_shape(K, N, false, ks, tw, n_wgs);
+  // measured at M = 1 (rotating weights): o 4096 x 4096 (128 workgroups) 6.6 -> 5.9 us and down
+  // 14336 x 4096 (128) 13.4 -> 10.8 us with 2 splits; qkv 4096 x 6144 (192 workgroups) LOSES (7.2 -> 7.9)
+  int sp = forced > 0 ? forced : (n_wgs <= 160 ? (n_wgs <= 80 ? 4 : 2) : 1);
+  // every (workgroup, in-workgroup slice) keeps at least 4 chunks of K
+  while (sp > 1 && (K / 64) / ((int64_t)ks * sp) < 4) sp >>= 1;
+  return sp < 1 ? 1 : sp;
+}
+
+void launch_gemv(const GemmKParams& kp, int dtype, int ng, hipStream_t st) {
+  GemvParams gp;
+  gp.a = kp.a; gp.wq = kp.wq; gp.sz = kp.sz; gp.bias = kp.bias; gp.c = kp.c;
+  gp.M = kp.M; gp.K = kp.K; gp.N = kp.N; gp.lda = kp.lda; gp.ldc = kp.ldc;
+  gp.gs_shift = kp.gs_shift;
+  gp.n64 = (int)(kp.K / 64);
   gp.silu = kp.silu;
-  if (kp.silu && ks == 8) ks = 4;  // a (gate, up) tile pair has to share the workgroup: tw >= 2
-  gp.ks = ks;
-  gp.tw = 8 / ks;
-  const int n_wgs = (int)((tiles + gp.tw - 1) / gp.tw);
+  int n_wgs;
+  gemv_shape(kp.K, kp.N, kp.silu != 0, gp.ks, gp.tw, n_wgs);
+  gp.n_wgs = n_wgs;
+  gp.splits = kp.split_k > 1 ? kp.split_k : 1;
+  gp.part = kp.part;
   const int mt = kp.M <= 1 ? 1 : kp.M <= 2 ? 2 : 4;
   const size_t lds = (size_t)mt * kp.K * 2 + (size_t)mt * (kp.K / 32) * 4 + 8 * mt * 32 * 4;
   if (dtype == SLM_BF16) {

@@ -545,14 +545,16 @@ def apply_rotary_pos_emb(query: torch.Tensor, key: torch.Tensor, positions: torc
             raise SlmError("partials: value must be the [n_tokens, n_kv_heads, head_dim] slice of the qkv buffer")
         # the three slices must be [q | k | v] of one row-major [n_tokens, n_cols] buffer
         es = query.element_size()
-        if not (query.stride(0) == key.stride(0) == value.stride(0) == n_cols and
+        one_row = query.size(0) == 1  # (the stride of a size-1 dimension is arbitrary)
+        if not ((one_row or query.stride(0) == key.stride(0) == value.stride(0) == n_cols) and
                 key.data_ptr() == query.data_ptr() + query.size(1) * query.size(2) * es and
                 value.data_ptr() == key.data_ptr() + key.size(1) * key.size(2) * es):
             raise SlmError("partials: query / key / value must be the [q | k | v] column slices of "
                            "the fused qkv GEMM output")
+        ts = n_cols  # token stride of all three slices
         check(L.slm_rope_kv_append_splitk(
-            partials.ptr, partials.splits, query.data_ptr(), query.stride(0), key.data_ptr(),
-            key.stride(0), value.data_ptr(), value.stride(0), positions.data_ptr(),
+            partials.ptr, partials.splits, query.data_ptr(), ts, key.data_ptr(),
+            ts, value.data_ptr(), ts, positions.data_ptr(),
             cos_sin.data_ptr(), is_f32, int(rotary_dim), 1 if interleaved else 0,
             slot_ids.data_ptr() if append else None, key_cache.data_ptr() if append else None,
             value_cache.data_ptr() if append else None, query.size(0), query.size(1), key.size(1),

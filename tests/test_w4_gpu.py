@@ -283,7 +283,7 @@ def test_repeated_launches_are_bit_identical(M, K, N, env, tune):
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("M,K,N", [(256, 4096, 4096), (256, 14336, 4096), (32, 4096, 4096),
-                                   (32, 14336, 4096), (7, 4096, 1024), (1, 4096, 4096)])
+                                   (32, 14336, 4096), (7, 4096, 1024)])
 def test_deferred_splitk_reduce_into_rms_norm(M, K, N, dtype):
     """SLM_W4_DEFER_REDUCE: a split-K GEMM leaves its fp32 slabs in the workspace and
     slm_rms_norm_splitk sums them itself -- same order and rounding as the reduce kernel, so
@@ -317,6 +317,51 @@ def test_deferred_splitk_reduce_into_rms_norm(M, K, N, dtype):
     kernels.rms_norm(out_b, c2, w, 1e-5, partials=h)
     torch.cuda.synchronize()
     assert torch.equal(out_b, out_b_ref)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("M,K,N,knobs", [(1, 4096, 4096, {}), (1, 14336, 4096, {}), (1, 4096, 6144, {}),
+                                         (3, 4096, 4096, {"SLM_W4_GEMV": 2}), (1, 4096, 28672, {}),
+                                         (1, 8192, 1280, {})])
+def test_gemv_splits_k_across_workgroups_only_for_a_deferred_consumer(M, K, N, knobs, dtype, tune):
+    """M = 1: the GEMV normally splits K inside its workgroups (no partials).  When the caller
+    defers the reduction anyway (RMSNorm / RoPE + append take fp32 slabs), a NARROW layer is also
+    split across workgroups so that its launch covers all the CUs (o_proj: 128 -> 256 workgroups).
+    The consumer then sees T(sum of the slabs in slab order); the undeferred GEMV sums K in a
+    different association, so the two agree to fp32 rounding, not bit for bit -- checked both ways."""
+    from scalellm_amd import kernels
+    tune(**knobs)
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
+    case = helpers.make_quant_case(M + K + N, K, N, 128, "awq", dtype)
+    packed = _pack(case, dtype)
+    g = torch.Generator(device=DEV).manual_seed(K + N)
+    a = torch.randn(M, K, device=DEV, dtype=tdt, generator=g)
+    w = (1 + 0.1 * torch.randn(N, device=DEV, generator=g)).to(tdt)
+    res0 = torch.randn(M, N, device=DEV, dtype=tdt, generator=g)
+    c = torch.empty(M, N, device=DEV, dtype=tdt)
+    assert not kernels.gptq_gemm(a, packed, c)                      # the ordinary GEMV
+    c2 = torch.full_like(c, float("nan"))
+    h = kernels.gptq_gemm(a, packed, c2, defer_reduce=True)
+    wide = N >= 6144  # (qkv 4096 x 6144 = 192 workgroups already: splitting it measured slower)
+    assert bool(h) == (not wide), "narrow layers are split across workgroups, wide ones are not"
+    if not h:
+        assert torch.equal(c2, c)
+        return
+    assert 2 <= int(h) <= 4 and torch.isnan(c2.float()).all()       # c is not written
+    slabs = h._keep[:int(h) * M * N * 4].view(torch.float32).view(int(h), M, N).clone()
+    x = slabs[0].clone()
+    for s_ in range(1, int(h)):
+        x = x + slabs[s_]                                            # slab order, fp32
+    x = x.to(tdt)
+    out, res = torch.empty_like(c), res0.clone()
+    kernels.rms_norm(out, c2, w, 1e-5, res, partials=h)
+    out_ref, res_ref = torch.empty_like(c), res0.clone()
+    kernels.rms_norm(out_ref, x, w, 1e-5, res_ref)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_ref) and torch.equal(res, res_ref)
+    # against the undeferred GEMV: same value up to the fp32 summation order (<= 1 ulp of T)
+    rel = float((x.float() - c.float()).abs().mean() / c.float().abs().mean())
+    assert rel < (4e-3 if dtype == "bf16" else 5e-4), rel
 
 
 def test_gemm_linearity_and_strided_rows():
