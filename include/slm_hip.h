@@ -235,6 +235,34 @@ SLM_API size_t slm_w4a16_gemm_workspace_bytes(const slm_w4_gemm_args* a);
 SLM_API int32_t slm_w4a16_gemm_deferred_splits(const slm_w4_gemm_args* a);
 SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream);
 
+/* The M <= 4 GEMV with the RMSNorm that feeds it computed in its prologue: at batch 1 a decoder
+ * layer is launch-bound, and the norm before the qkv and gate_up projections
+ * (input_layernorm_ / post_attention_layernorm_, src/models/meta/llama.h:174-176) is 8 KiB of work per token.
+ *   h      = T(x) + residual_in            (fp32; x given directly or as split-K slabs)
+ *   a      = rms_norm(h) * weight          (what the GEMV consumes; never leaves the chip unless
+ *                                           normed_out is given)
+ *   residual_out = T(h)
+ * followed by the GEMM of `a` exactly as slm_w4a16_gemm does it (a->a and a->lda are ignored;
+ * flags as usual).  Bit-identical to slm_rms_norm / slm_rms_norm_splitk followed by
+ * slm_w4a16_gemm.  Every workgroup recomputes the norm while workgroup 0 stores residual_out /
+ * normed_out, hence residual_out may not overlap residual_in or x (double-buffer the residual);
+ * SLM_ERR_INVALID_ARG otherwise.  SLM_ERR_UNSUPPORTED unless slm_w4a16_gemv_norm_supported(a). */
+typedef struct slm_w4_norm_prologue {
+  const void* x;           /* [M, K] T contiguous, or NULL when `partials` is given         */
+  const float* partials;   /* [n_splits, M, K] fp32 slabs of a deferred GEMM, or NULL       */
+  int32_t n_splits;
+  float eps;
+  const void* residual_in; /* [M, K] T or NULL (plain rms_norm)                             */
+  void* residual_out;      /* [M, K] T, required with residual_in                           */
+  const void* weight;      /* [K] T                                                         */
+  void* normed_out;        /* optional [M, K] T copy of the normalised activations          */
+} slm_w4_norm_prologue;
+/* 1 when the argument block would take the GEMV path (M <= 4, supported group size, no act-order
+ * permutation, the extra fp32 row fits the LDS): a pure function of the block and the tuning table */
+SLM_API int32_t slm_w4a16_gemv_norm_supported(const slm_w4_gemm_args* a);
+SLM_API int slm_w4a16_gemv_norm(const slm_w4_gemm_args* a, const slm_w4_norm_prologue* np,
+                                void* stream);
+
 /* Slow dequantise-to-dense helper (debug / parity): w_out [K, N] T.          */
 SLM_API int slm_w4_dequant(const void* wq, const void* sz, int64_t K, int64_t N,
                            int64_t group_size, int32_t dtype, void* w_out, void* stream);

@@ -55,6 +55,15 @@ SLM_W4_DEFER_REDUCE = 1
 SLM_W4_SILU_MUL = 2
 
 
+class W4NormPrologue(C.Structure):
+    """struct slm_w4_norm_prologue (include/slm_hip.h)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("partials", C.c_void_p), ("n_splits", C.c_int32), ("eps", C.c_float),
+        ("residual_in", C.c_void_p), ("residual_out", C.c_void_p), ("weight", C.c_void_p),
+        ("normed_out", C.c_void_p),
+    ]
+
+
 class ArArgs(C.Structure):
     """struct slm_ar_args (include/slm_hip.h)."""
     _fields_ = [
@@ -113,6 +122,8 @@ def lib() -> C.CDLL:
         ("slm_w4a16_gemm_workspace_bytes", C.c_size_t, [C.POINTER(W4GemmArgs)]),
         ("slm_w4a16_gemm", C.c_int, [C.POINTER(W4GemmArgs), C.c_void_p]),
         ("slm_w4a16_gemm_deferred_splits", C.c_int32, [C.POINTER(W4GemmArgs)]),
+        ("slm_w4a16_gemv_norm_supported", C.c_int32, [C.POINTER(W4GemmArgs)]),
+        ("slm_w4a16_gemv_norm", C.c_int, [C.POINTER(W4GemmArgs), C.POINTER(W4NormPrologue), C.c_void_p]),
         ("slm_rms_norm_splitk", C.c_int,
          [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float,
           C.c_int32, C.c_void_p]),

@@ -754,14 +754,39 @@ SLM_API int32_t slm_w4a16_gemm_deferred_splits(const slm_w4_gemm_args* a) {
   return (a->flags & SLM_W4_DEFER_REDUCE) && !a->bias && pl.split_k > 1 ? pl.split_k : 0;
 }
 
-SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream) {
+}  // extern "C"
+
+// np != NULL: the activations are produced by the GEMV's norm prologue (slm_w4a16_gemv_norm)
+static int gemm_impl(const slm_w4_gemm_args* a, const slm_w4_norm_prologue* np, void* stream) {
   GemmPlan pl;
   int rc = plan_gemm(a, &pl);
   if (rc != SLM_OK) return rc;
+  if (np && (!pl.gemv || a->perm || !gemv_supported(a->M, a->K, a->group_size, true)))
+    return SLM_ERR_UNSUPPORTED;
   if (a->M == 0) return SLM_OK;
-  if (!a->a || !a->wq || !a->sz || !a->c) return SLM_ERR_INVALID_ARG;
+  if ((!np && !a->a) || !a->wq || !a->sz || !a->c) return SLM_ERR_INVALID_ARG;
   const bool silu = (a->flags & SLM_W4_SILU_MUL) != 0;
-  if (!aligned16(a->a) || !aligned16(a->wq) || a->lda % 8 || a->lda < a->K ||
+  if (np) {
+    // exactly one activation source; the residual is double-buffered: every workgroup recomputes
+    // x + residual_in while workgroup 0 stores residual_out, so the two must not share memory
+    if (!np->weight || (np->x != nullptr) == (np->partials != nullptr) ||
+        (np->partials && np->n_splits < 1) || (np->residual_in && !np->residual_out))
+      return SLM_ERR_INVALID_ARG;
+    const size_t row_bytes = (size_t)a->M * a->K * 2;
+    auto overlaps = [&](const void* w, const void* r) {
+      const char* wp = reinterpret_cast<const char*>(w);
+      const char* rp = reinterpret_cast<const char*>(r);
+      return w && r && wp < rp + row_bytes && rp < wp + row_bytes;
+    };
+    if (overlaps(np->residual_out, np->residual_in) || overlaps(np->residual_out, np->x) ||
+        overlaps(np->normed_out, np->residual_in) || overlaps(np->normed_out, np->x) ||
+        overlaps(np->normed_out, np->residual_out))
+      return SLM_ERR_INVALID_ARG;
+    if (!aligned16(np->x) || !aligned16(np->partials) || !aligned16(np->residual_in) ||
+        !aligned16(np->residual_out) || !aligned16(np->weight) || !aligned16(np->normed_out))
+      return SLM_ERR_ALIGNMENT;
+  }
+  if ((!np && (!aligned16(a->a) || a->lda % 8 || a->lda < a->K)) || !aligned16(a->wq) ||
       a->ldc < (silu ? a->N / 2 : a->N))
     return SLM_ERR_ALIGNMENT;
   if ((pl.part_bytes + pl.aperm_bytes) > 0 &&
@@ -772,6 +797,13 @@ SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream) {
 
   GemmKParams kp;
   kp.a = a->a; kp.lda = a->lda;
+  kp.norm_weight = nullptr;
+  if (np) {
+    kp.a = nullptr; kp.lda = a->K;
+    kp.norm_x = np->x; kp.norm_part = np->partials; kp.norm_splits = np->n_splits;
+    kp.norm_eps = np->eps; kp.norm_res_in = np->residual_in; kp.norm_res_out = np->residual_out;
+    kp.norm_weight = np->weight; kp.norm_out = np->normed_out;
+  }
   if (a->perm) {  // act-order: gather the activation columns once (gptq_gemm.cu:69-118)
     uint16_t* ap = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(a->workspace) + pl.part_bytes);
     const unsigned gx = (unsigned)((a->K + 255) / 256);
@@ -822,6 +854,24 @@ SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream) {
     rc = hip_check_launch();
   }
   return rc;
+}
+
+extern "C" {
+
+SLM_API int slm_w4a16_gemm(const slm_w4_gemm_args* a, void* stream) {
+  return gemm_impl(a, nullptr, stream);
+}
+
+SLM_API int32_t slm_w4a16_gemv_norm_supported(const slm_w4_gemm_args* a) {
+  GemmPlan pl;
+  if (!a || plan_gemm(a, &pl) != SLM_OK) return 0;
+  return pl.gemv && !a->perm && gemv_supported(a->M, a->K, a->group_size, true) ? 1 : 0;
+}
+
+SLM_API int slm_w4a16_gemv_norm(const slm_w4_gemm_args* a, const slm_w4_norm_prologue* np,
+                                void* stream) {
+  if (!a || !np) return SLM_ERR_INVALID_ARG;
+  return gemm_impl(a, np, stream);
 }
 
 }  // extern "C"

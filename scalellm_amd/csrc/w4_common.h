@@ -89,6 +89,16 @@ struct GemmKParams {
   int chunks_per_split;
   int n_mblocks, n_nblocks;
   int silu;  // SLM_W4_SILU_MUL: column tiles are (gate, up) pairs, c is [M, N/2]
+  // GEMV norm prologue (slm_w4a16_gemv_norm): activations = rms_norm(x + residual_in) * weight,
+  // computed in the kernel; norm_weight == NULL: none, `a` is read as usual
+  const void* norm_x;          // [M, K] T or NULL
+  const float* norm_part;      // [norm_splits, M, K] fp32 or NULL
+  int norm_splits;
+  float norm_eps;
+  const void* norm_res_in;     // [M, K] T or NULL
+  void* norm_res_out;          // [M, K] T
+  const void* norm_weight;     // [K] T
+  void* norm_out;              // optional [M, K] T copy of the normalised activations
 };
 
 template <typename T>
@@ -155,7 +165,8 @@ __device__ __forceinline__ void store_ct_silu_pair(const GemmKParams& p, const f
 constexpr int W4_KC = 128;  // K granularity of the plan (split-K units, LDS chunk of the small-M kernels)
 
 // dot2 GEMV for M <= 4 (w4_gemv.hip): no MFMA, activations resident in LDS, K split inside the workgroup
-bool gemv_supported(int64_t M, int64_t K, int64_t group_size);
+// norm: with the RMSNorm prologue (one more fp32 row in LDS)
+bool gemv_supported(int64_t M, int64_t K, int64_t group_size, bool norm = false);
 void launch_gemv(const GemmKParams& kp, int dtype, int ng, hipStream_t st);
 // K splits across workgroups (1 = none; > 1 only when the caller takes fp32 partial slabs)
 int gemv_global_splits(int64_t M, int64_t K, int64_t N, bool partials_ok);

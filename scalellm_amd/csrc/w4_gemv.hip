@@ -37,6 +37,9 @@ struct GemvParams {
   int splits;    // K splits across workgroups (> 1: fp32 partial slabs to `part`, c not written)
   int n_wgs;     // workgroups per split
   float* part;   // [splits][M][N]
+  // norm prologue (GemmKParams): norm_weight == NULL -> activations come from `a`
+  const void* norm_x; const float* norm_part; int norm_splits; float norm_eps;
+  const void* norm_res_in; void* norm_res_out; const void* norm_weight; void* norm_out;
   int silu;      // SLM_W4_SILU_MUL: tw is even, tiles (2j, 2j+1) = (gate, up), c is [M, N/2]
 };
 
@@ -44,10 +47,13 @@ constexpr int GV_RING = 8;  // weight ring depth (64-deep chunks per wave)
 
 // NGC: scale groups per 64-deep chunk (2 for group 32, 1 otherwise); MT: token rows (1, 2, 4)
 // REFILL: the K slice of a wave is longer than the ring (otherwise every chunk is preloaded)
-template <typename T, int NGC, int MT, bool REFILL>
+// NORM: RMSNorm prologue (slm_w4a16_gemv_norm); its own instantiation so that the plain kernel keeps
+// its register count
+template <typename T, int NGC, int MT, bool REFILL, bool NORM>
 __global__ void __launch_bounds__(512) w4a16_gemv_kernel(const GemvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // LDS: A [MT][K] T | X32 [MT][K/32] f32 (activation sums per 32 of K) | reduction [8][MT][32] f32
+  // (| NORM: h [K] f32 | 4 f32)
   const int n32 = (int)(p.K / 32);
   uint16_t* a_lds = reinterpret_cast<uint16_t*>(smem);
   float* x_lds = reinterpret_cast<float*>(smem + (size_t)MT * p.K * 2);
@@ -97,7 +103,88 @@ __global__ void __launch_bounds__(512) w4a16_gemv_kernel(const GemvParams p) {
   }
 
   // ---- phase 0: activations -> LDS (rows >= M replicate the last row; never stored) ----
-  {
+  if constexpr (NORM) {
+    // Norm prologue: a[m, :] = rms_norm(x[m, :] + residual[m, :]) * weight, with x possibly given
+    // as the fp32 split-K slabs of the producing GEMM -- the arithmetic, the thread -> column
+    // mapping and the reduction tree of rms_norm_kernel (glue.hip), executed by the first 256
+    // threads of EVERY workgroup (a 4096-wide row is 8 KiB of L2 hits: cheaper to recompute per
+    // workgroup than to launch a kernel for it).  Workgroup 0 also stores the updated residual
+    // (and, if asked, the normalised row) -- into buffers nobody reads during this launch.
+    // h = x + residual (fp32) waits in LDS between the two passes (a thread reads back only what
+    // it wrote itself); two vectors per thread are in flight per trip.
+    float* h_lds = red + 8 * MT * 32;  // [K] fp32, one row at a time
+    float* nred = h_lds + p.K;         // [4] (dynamic too: static LDS on top of a 160 KiB opt-in fails the launch)
+    const int64_t dim = p.K, nvec = dim / 8;
+    const bool writer = blockIdx.x == 0;
+    auto load_h = [&](int64_t mc, int64_t vi, float (&f)[8]) {
+      u32x4 a;
+      if (p.norm_part) {
+        const f32x4 s0 = splitk_sum4(p.norm_part + mc * dim + vi * 8, p.M * dim, p.norm_splits);
+        const f32x4 s1 = splitk_sum4(p.norm_part + mc * dim + vi * 8 + 4, p.M * dim, p.norm_splits);
+        a.x = pack2<T>(s0.x, s0.y); a.y = pack2<T>(s0.z, s0.w);
+        a.z = pack2<T>(s1.x, s1.y); a.w = pack2<T>(s1.z, s1.w);
+      } else {
+        a = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(p.norm_x) + mc * dim + vi * 8);
+      }
+      f[0] = lo_f32<T>(a.x); f[1] = hi_f32<T>(a.x); f[2] = lo_f32<T>(a.y); f[3] = hi_f32<T>(a.y);
+      f[4] = lo_f32<T>(a.z); f[5] = hi_f32<T>(a.z); f[6] = lo_f32<T>(a.w); f[7] = hi_f32<T>(a.w);
+      if (p.norm_res_in) {
+        const u32x4 r = *reinterpret_cast<const u32x4*>(
+            reinterpret_cast<const uint16_t*>(p.norm_res_in) + mc * dim + vi * 8);
+        f[0] += lo_f32<T>(r.x); f[1] += hi_f32<T>(r.x); f[2] += lo_f32<T>(r.y); f[3] += hi_f32<T>(r.y);
+        f[4] += lo_f32<T>(r.z); f[5] += hi_f32<T>(r.z); f[6] += lo_f32<T>(r.w); f[7] += hi_f32<T>(r.w);
+      }
+    };
+    auto keep_h = [&](int m, int64_t mc, int64_t vi, const float (&f)[8], float ss) {
+      if (p.norm_res_in && writer && m < p.M) {
+        u32x4 w;
+        w.x = pack2<T>(f[0], f[1]); w.y = pack2<T>(f[2], f[3]);
+        w.z = pack2<T>(f[4], f[5]); w.w = pack2<T>(f[6], f[7]);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.norm_res_out) + mc * dim + vi * 8) = w;
+      }
+      *reinterpret_cast<f32x4*>(h_lds + vi * 8) = f32x4{f[0], f[1], f[2], f[3]};
+      *reinterpret_cast<f32x4*>(h_lds + vi * 8 + 4) = f32x4{f[4], f[5], f[6], f[7]};
+      return rms_sumsq8(f, ss);
+    };
+    // the norm weights of the first trip depend on nothing: in flight before the activations
+    const uint16_t* nw = reinterpret_cast<const uint16_t*>(p.norm_weight);
+    const int64_t tv = tid & 255;
+    const u32x4 wpre0 = *reinterpret_cast<const u32x4*>(nw + (tv < nvec ? tv : nvec - 1) * 8);
+    const u32x4 wpre1 = *reinterpret_cast<const u32x4*>(nw + (tv + 256 < nvec ? tv + 256 : nvec - 1) * 8);
+    for (int m = 0; m < MT; ++m) {
+      const int64_t mc = m < p.M ? m : p.M - 1;
+      if (tid < 256) {
+        float ss = 0.f;
+        for (int64_t v0 = tid; v0 < nvec; v0 += 512) {  // ascending vi per thread, as rms_norm_kernel
+          const int64_t v1 = v0 + 256;
+          float f0[8], f1[8];
+          load_h(mc, v0, f0);
+          load_h(mc, v1 < nvec ? v1 : v0, f1);  // unconditional: both trips in flight together
+          ss = keep_h(m, mc, v0, f0, ss);
+          if (v1 < nvec) ss = keep_h(m, mc, v1, f1, ss);
+        }
+        ss = group_sum<64>(ss);
+        if ((tid & 63) == 0) nred[tid >> 6] = ss;
+      }
+      __syncthreads();
+      if (tid < 256) {
+        const float tot = nred[0] + nred[1] + nred[2] + nred[3];
+        const float rs = rsqrtf(tot / (float)dim + p.norm_eps);
+        for (int64_t vi = tid; vi < nvec; vi += 256) {
+          const u32x4 wv = vi == tid ? wpre0 : vi == tid + 256 ? wpre1
+                                             : *reinterpret_cast<const u32x4*>(nw + vi * 8);
+          const f32x4 h0 = *reinterpret_cast<const f32x4*>(h_lds + vi * 8);
+          const f32x4 h1 = *reinterpret_cast<const f32x4*>(h_lds + vi * 8 + 4);
+          const float f[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+          const u32x4 o = rms_apply8<T>(f, rs, wv);
+          *reinterpret_cast<u32x4*>(a_lds + (size_t)m * p.K + vi * 8) = o;
+          if (writer && p.norm_out && m < p.M)
+            *reinterpret_cast<u32x4*>(reinterpret_cast<uint16_t*>(p.norm_out) + mc * dim + vi * 8) = o;
+        }
+      }
+      __syncthreads();  // nred and h_lds are reused by the next row
+    }
+  } else {
     const int vec_per_row = (int)(p.K / 8);
     for (int v = tid; v < MT * vec_per_row; v += 512) {
       const int m = v / vec_per_row, kk = v - m * vec_per_row;
@@ -268,7 +355,11 @@ static void launch_gemv_m(const GemvParams& gp, int n_wgs, size_t lds, hipStream
                       tune_get(TUNE_W4_GEMV_REFILL, 1) != 0;
 #define SLM_GEMV(MTT)                                                                          \
   do {                                                                                         \
-    auto kfn = refill ? w4a16_gemv_kernel<T, NGC, MTT, true> : w4a16_gemv_kernel<T, NGC, MTT, false>; \
+    auto kfn = gp.norm_weight                                                                  \
+                   ? (refill ? w4a16_gemv_kernel<T, NGC, MTT, true, true>                      \
+                             : w4a16_gemv_kernel<T, NGC, MTT, false, true>)                    \
+                   : (refill ? w4a16_gemv_kernel<T, NGC, MTT, true, false>                     \
+                             : w4a16_gemv_kernel<T, NGC, MTT, false, false>);                  \
     if (lds > 65536) {                                                                         \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \
@@ -281,10 +372,11 @@ static void launch_gemv_m(const GemvParams& gp, int n_wgs, size_t lds, hipStream
 #undef SLM_GEMV
 }
 
-bool gemv_supported(int64_t M, int64_t K, int64_t group_size) {
+bool gemv_supported(int64_t M, int64_t K, int64_t group_size, bool norm) {
   if (M < 1 || M > 4) return false;
   const int mt = M <= 1 ? 1 : M <= 2 ? 2 : 4;
-  const size_t lds = (size_t)mt * K * 2 + (size_t)mt * (K / 32) * 4 + 8 * mt * 32 * 4;
+  const size_t lds = (size_t)mt * K * 2 + (size_t)mt * (K / 32) * 4 + 8 * mt * 32 * 4 +
+                     (norm ? (size_t)K * 4 + 16 : 0);
   (void)group_size;
   return lds <= 160 * 1024 && K % 64 == 0;  // (the < 4 GiB checks are in launch_gemv's caller)
 }
@@ -333,8 +425,12 @@ void launch_gemv(const GemmKParams& kp, int dtype, int ng, hipStream_t st) {
   gp.n_wgs = n_wgs;
   gp.splits = kp.split_k > 1 ? kp.split_k : 1;
   gp.part = kp.part;
+  gp.norm_x = kp.norm_x; gp.norm_part = kp.norm_part; gp.norm_splits = kp.norm_splits;
+  gp.norm_eps = kp.norm_eps; gp.norm_res_in = kp.norm_res_in; gp.norm_res_out = kp.norm_res_out;
+  gp.norm_weight = kp.norm_weight; gp.norm_out = kp.norm_out;
   const int mt = kp.M <= 1 ? 1 : kp.M <= 2 ? 2 : 4;
-  const size_t lds = (size_t)mt * kp.K * 2 + (size_t)mt * (kp.K / 32) * 4 + 8 * mt * 32 * 4;
+  const size_t lds = (size_t)mt * kp.K * 2 + (size_t)mt * (kp.K / 32) * 4 + 8 * mt * 32 * 4 +
+                     (kp.norm_weight ? (size_t)kp.K * 4 + 16 : 0);  // + one fp32 row of the norm prologue
   if (dtype == SLM_BF16) {
     if (ng == 4) launch_gemv_m<bf16_tag, 2>(gp, n_wgs, lds, st);
     else launch_gemv_m<bf16_tag, 1>(gp, n_wgs, lds, st);

@@ -107,6 +107,10 @@ class LlamaDecodeStep:
         self.custom_ar = custom_allreduce
         self.shape, self.pa, self.dtype, self.device = shape, pa, dtype, torch.device(device)
         self.defer_splitk = os.environ.get("SLM_DEFER_SPLITK", "1") != "0"  # read once, at build time
+        # <= 4 tokens on one rank: the RMSNorm before the qkv / gate_up projections runs in the
+        # GEMV's prologue (kernels.NormPrologue) -- two launches less per layer where the step is
+        # launch-bound.  Identical bits either way.
+        self.fold_norm = os.environ.get("SLM_FOLD_NORM", "1") != "0"
         tp = pa.world_size
         assert shape.n_heads % tp == 0 and shape.intermediate % tp == 0 and shape.hidden % tp == 0
         self.n_heads = shape.n_heads // tp
@@ -175,7 +179,8 @@ class LlamaDecodeStep:
         self.kv_head0 = kv_head0
         T = max_batch_tokens
         e = lambda *s: torch.empty(*s, dtype=dtype, device=self.device)  # noqa: E731
-        self.buf = dict(resid=e(T, H), normed=e(T, H), qkv=e(T, qkv_n), attn=e(T, self.n_heads, D),
+        self.buf = dict(resid=e(T, H), resid_alt=e(min(T, 4), H), normed=e(T, H), qkv=e(T, qkv_n),
+                        attn=e(T, self.n_heads, D),
                         o=e(T, H), gate_up=None if fuse_silu else e(T, 2 * shape.intermediate // tp),
                         act=e(T, shape.intermediate // tp), down=e(T, H))
         if kv_fill != "none":
@@ -242,39 +247,72 @@ class LlamaDecodeStep:
             resid.copy_(x)
             o_buf, down_buf = b["o"][:T], b["down"][:T]
 
-        def reduce_add_norm(i: int, partial: torch.Tensor, weight: torch.Tensor, deferred=None) -> None:
-            """normed = RMSNorm(all-reduce(partial) + resid) * weight, resid updated in place
-            (reduce_from_model_parallel_region + rms_norm_residual, or the fused launch)."""
+        # A norm that has not run yet: (x, deferred slabs of x or None, residual or None, weight).
+        # It either folds into the projection that consumes it (norm_then) or runs on its own.
+        fold = self.fold_norm and pa.world_size == 1 and T <= 4
+        state = {"resid": resid, "alt": b["resid_alt"][:T] if fold else None}
+
+        def run_norm(pend) -> None:
+            x, deferred, res, weight = pend
+            kernels.rms_norm(normed, x, weight, s.rms_eps, residual=res, partials=deferred)
+
+        def reduce_add_norm(i: int, partial: torch.Tensor, weight: torch.Tensor, deferred=None):
+            """normed = RMSNorm(all-reduce(partial) + resid) * weight, resid updated
+            (reduce_from_model_parallel_region + rms_norm_residual, or the fused launch).
+            Returns the norm still to be run when it may fold into its consumer, else None."""
             if ar is not None:
                 ar.allreduce_residual_rmsnorm(i, T, normed, resid, weight, s.rms_eps)
-            else:
-                if pa.world_size > 1:
-                    pa.process_group.allreduce(partial)
-                kernels.rms_norm(normed, partial, weight, s.rms_eps, residual=resid,
-                                 partials=deferred)
+                return None
+            if pa.world_size > 1:
+                pa.process_group.allreduce(partial)
+            pend = (partial, deferred, state["resid"], weight)
+            if fold:
+                return pend
+            run_norm(pend)
+            return None
 
-        kernels.rms_norm(normed, resid, self.layers[0]["in_norm"], s.rms_eps)
+        def norm_then(lin, pend, out, defer_splitk=False):
+            """lin(RMSNorm(pend)): in one launch when the projection takes the norm as its prologue."""
+            if pend is None:
+                return lin.forward(normed, out=out, defer_splitk=defer_splitk)
+            if not lin.norm_supported(T, defer_splitk):
+                run_norm(pend)
+                return lin.forward(normed, out=out, defer_splitk=defer_splitk)
+            x, deferred, res, weight = pend
+            pro = kernels.NormPrologue(weight, s.rms_eps, residual=res, partials=deferred,
+                                       residual_out=state["alt"] if res is not None else None)
+            y = lin.forward(x, out=out, defer_splitk=defer_splitk, norm=pro)
+            if res is not None:  # the residual stream now lives in the other buffer
+                state["resid"], state["alt"] = state["alt"], state["resid"]
+            return y
+
+        pend = (resid, None, None, self.layers[0]["in_norm"])
+        if not fold:
+            run_norm(pend)
+            pend = None
         for li, L in enumerate(self.layers):
             # a split-K GEMM hands its fp32 slabs straight to its consumer (one launch and one
             # activation round trip less): qkv -> the RoPE + append kernel (any world size: the qkv
             # projection is column-parallel), o / down -> the RMSNorm (single rank)
-            qkv = L["qkv"].forward(normed, out=b["qkv"][:T], defer_splitk=self.defer_splitk)
+            qkv = norm_then(L["qkv"], pend, b["qkv"][:T], defer_splitk=self.defer_splitk)
             nq, nkv = self.n_heads * D, self.n_kv_heads * D
             q, k, v = qkv[:, :nq], qkv[:, nq:nq + nkv], qkv[:, nq + nkv:]
             attn = self.attn.forward(q, k, v, positions, L["kv"], params, output=b["attn"][:T],
                                      qkv_partials=L["qkv"].deferred if self.defer_splitk else None)
             defer = pa.world_size == 1 and self.defer_splitk
             delta = L["o"].forward(attn, out=o_buf, reduce=False, defer_splitk=defer)
-            reduce_add_norm(0, delta, L["post_norm"], L["o"].deferred if defer else None)
+            pend = reduce_add_norm(0, delta, L["post_norm"], L["o"].deferred if defer else None)
             if L["gate_up"].paired:  # SiLU*mul in the GEMM epilogue
-                L["gate_up"].forward(normed, out=b["act"][:T])
+                norm_then(L["gate_up"], pend, b["act"][:T])
             else:
-                gu = L["gate_up"].forward(normed, out=b["gate_up"][:T])
+                gu = norm_then(L["gate_up"], pend, b["gate_up"][:T])
                 kernels.silu_and_mul(b["act"][:T], gu)
             delta = L["down"].forward(b["act"][:T], out=down_buf, reduce=False, defer_splitk=defer)
             # the NEXT block's input norm (or the final norm) consumes this reduction
             nxt = self.layers[li + 1]["in_norm"] if li + 1 < len(self.layers) else self.final_norm
-            reduce_add_norm(1, delta, nxt, L["down"].deferred if defer else None)
+            pend = reduce_add_norm(1, delta, nxt, L["down"].deferred if defer else None)
+        if pend is not None:  # the final norm has no projection of ours behind it
+            run_norm(pend)
         last = (params.q_cu_seq_lens[1:] - 1).long()
         self.last_hidden = normed[last]  # final-norm output of each sequence's last token (tests)
         logits = self.last_hidden @ self.lm_head  # plain library GEMM (hipBLASLt): not on the graded path

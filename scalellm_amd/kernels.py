@@ -89,9 +89,10 @@ def clear_tuning() -> None:
 # final size.  Size it once up front with reserve_workspace() to avoid retirements.
 # ---------------------------------------------------------------------------------------
 _workspaces = {}
-_deferred_ws = {}
+_deferred_ws = {}    # slot 0
+_deferred_ws_b = {}  # slot 1: where a GEMM that CONSUMES slot-0 slabs (norm prologue) leaves its own
 _retired = []  # buffers replaced by bigger ones: still referenced by graphs captured before
-_deferred_gen = {}  # device -> generation counter of the deferred-partials buffer
+_deferred_gen = {}  # (device, slot) -> generation counter of that deferred-partials buffer
 
 
 def _dev_key(dev: torch.device):
@@ -129,11 +130,28 @@ class DeferredPartials:
     """Handle to the fp32 split-K slabs a gptq_gemm(..., defer_reduce=True) left behind, consumed
     by rms_norm(..., partials=handle).  Falsy when the GEMM wrote `c` as usual."""
 
-    __slots__ = ("ptr", "splits", "numel", "key", "generation", "_keep")
+    __slots__ = ("ptr", "splits", "numel", "key", "generation", "_keep", "slot")
 
-    def __init__(self, ptr=0, splits=0, numel=0, key=None, generation=0, keep=None):
+    def __init__(self, ptr=0, splits=0, numel=0, key=None, generation=0, keep=None, slot=0):
         self.ptr, self.splits, self.numel = ptr, splits, numel
-        self.key, self.generation, self._keep = key, generation, keep
+        self.key, self.generation, self._keep, self.slot = key, generation, keep, slot
+
+    @classmethod
+    def from_slabs(cls, slabs: torch.Tensor) -> "DeferredPartials":
+        """Handle over caller-owned fp32 partial sums [splits, M, N] (slot 2: never overwritten by
+        this module, so never stale; the caller keeps them alive and unmodified until consumed)."""
+        if slabs.dim() != 3 or slabs.dtype != torch.float32 or not slabs.is_contiguous() or \
+                not slabs.is_cuda or slabs.size(0) < 1:
+            raise SlmError("from_slabs takes a contiguous fp32 [splits, M, N] device tensor")
+        return cls(slabs.data_ptr(), slabs.size(0), slabs.size(1) * slabs.size(2),
+                   _dev_key(slabs.device), 0, slabs, 2)
+
+    def check(self, dev: torch.device, numel: int, who: str) -> None:
+        if self.key != _dev_key(dev) or self.numel != numel:
+            raise SlmError(f"{who}: the handle belongs to another device or shape")
+        if self.slot != 2 and _deferred_gen.get((self.key, self.slot)) != self.generation:
+            raise SlmError(f"{who}: stale handle -- a later deferred GEMM on this device has "
+                           "overwritten the slabs")
 
     def __bool__(self):
         return self.splits > 0
@@ -391,9 +409,43 @@ def _gemm_args(a, packed: PackedW4, c, bias, silu_mul=False) -> W4GemmArgs:
     return g
 
 
+class NormPrologue:
+    """RMSNorm computed inside the M <= 4 GEMV (struct slm_w4_norm_prologue): the activations of
+    gptq_gemm(x, ..., norm=NormPrologue(...)) are rms_norm(x + residual) * weight, where `x` is the
+    tensor passed as `a` -- or, with `partials`, the unwritten output of the deferred GEMM that
+    returned the handle.  residual_out receives T(x + residual) and may NOT alias residual or x
+    (every workgroup recomputes the sum while one of them stores it)."""
+
+    __slots__ = ("weight", "eps", "residual", "residual_out", "partials", "normed_out")
+
+    def __init__(self, weight: torch.Tensor, eps: float, residual: Optional[torch.Tensor] = None,
+                 residual_out: Optional[torch.Tensor] = None,
+                 partials: Optional[DeferredPartials] = None,
+                 normed_out: Optional[torch.Tensor] = None):
+        self.weight, self.eps, self.residual, self.residual_out = weight, eps, residual, residual_out
+        self.partials, self.normed_out = partials, normed_out
+
+
+def gemv_norm_supported(n_tokens: int, packed: PackedW4, dtype: torch.dtype,
+                        silu_mul: bool = False, defer_reduce: bool = False) -> bool:
+    """Would gptq_gemm(..., norm=...) be accepted for this shape (slm_w4a16_gemv_norm_supported)?"""
+    if n_tokens <= 0 or packed.perm is not None or dtype != packed.dtype:
+        return False
+    g = W4GemmArgs()
+    g.a, g.wq, g.sz = None, packed.wq.data_ptr(), packed.sz.data_ptr()
+    g.perm, g.bias, g.c = None, None, None
+    g.M, g.K, g.N = n_tokens, packed.K, packed.N
+    g.lda, g.ldc = packed.K, packed.N // 2 if silu_mul else packed.N
+    g.group_size = packed.group_size
+    g.dtype = SLM_BF16 if dtype == torch.bfloat16 else SLM_F16
+    g.flags = _lib.SLM_W4_SILU_MUL if silu_mul else (_lib.SLM_W4_DEFER_REDUCE if defer_reduce else 0)
+    g.workspace, g.workspace_bytes = None, 0
+    return bool(_lib.lib().slm_w4a16_gemv_norm_supported(C.byref(g)))
+
+
 def gptq_gemm(a: torch.Tensor, packed: PackedW4, c: torch.Tensor,
               bias: Optional[torch.Tensor] = None, defer_reduce: bool = False,
-              silu_mul: bool = False) -> DeferredPartials:
+              silu_mul: bool = False, norm: Optional[NormPrologue] = None) -> DeferredPartials:
     """Mirror of marlin::gptq_gemm (marlin.h:17-25): C[M,N] = A[M,K] . dequant(W) (+ bias),
     fp32 accumulate, written into the pre-allocated `c`.  AWQ and GPTQ share it, as in the
     reference (has_zp true/false): zero points live in the prepacked scale/zero table.
@@ -405,13 +457,43 @@ def gptq_gemm(a: torch.Tensor, packed: PackedW4, c: torch.Tensor,
 
     silu_mul: `packed` is a paired (gate | up) weight and `c` is [M, N/2]: the epilogue applies
     kernel::act_and_mul (activation_kernels.cu:84) -- c = silu(gate) * up, bit-identical to the
-    unfused GEMM followed by silu_mul()."""
+    unfused GEMM followed by silu_mul().
+
+    norm: the activations are rms_norm(a + norm.residual) * norm.weight, computed in the GEMV's
+    prologue (M <= 4 only: ask gemv_norm_supported first) -- bit-identical to rms_norm() followed
+    by this call, two launches less per decoder layer at batch 1."""
     L = _lib.lib()
     if silu_mul and defer_reduce:
         raise SlmError("silu_mul and defer_reduce cannot be combined")
     g = _gemm_args(a, packed, c, bias, silu_mul)
     if g.M == 0:
         return DeferredPartials()
+    npro, slot = None, 0
+    if norm is not None:
+        _require_gpu(norm.weight, norm.residual, norm.residual_out, norm.normed_out)
+        for t in (a, norm.weight, norm.residual, norm.residual_out, norm.normed_out):
+            if t is not None and (not t.is_contiguous() or t.dtype != a.dtype):
+                raise SlmError("norm prologue tensors must be contiguous and of the activation dtype")
+        for t in (norm.residual, norm.residual_out, norm.normed_out):
+            if t is not None and t.shape != a.shape:
+                raise SlmError("norm prologue: residual / residual_out / normed_out must be [M, K]")
+        if norm.weight.numel() != packed.K:
+            raise SlmError("norm prologue: weight must have K entries")
+        if norm.residual is not None and norm.residual_out is None:
+            raise SlmError("norm prologue: residual needs a separate residual_out buffer")
+        npro = _lib.W4NormPrologue()
+        npro.x, npro.partials, npro.n_splits = a.data_ptr(), None, 0
+        if norm.partials:
+            if not isinstance(norm.partials, DeferredPartials):
+                raise SlmError("norm.partials takes the handle gptq_gemm(defer_reduce=True) returned")
+            norm.partials.check(a.device, a.numel(), "norm prologue")
+            npro.x, npro.partials, npro.n_splits = None, norm.partials.ptr, norm.partials.splits
+            slot = 1 if norm.partials.slot == 0 else 0  # its own slabs must not land on the ones it reads
+        npro.eps = float(norm.eps)
+        npro.residual_in = norm.residual.data_ptr() if norm.residual is not None else None
+        npro.residual_out = norm.residual_out.data_ptr() if norm.residual_out is not None else None
+        npro.weight = norm.weight.data_ptr()
+        npro.normed_out = norm.normed_out.data_ptr() if norm.normed_out is not None else None
     if silu_mul:
         g.flags = _lib.SLM_W4_SILU_MUL
     deferred = 0
@@ -425,15 +507,18 @@ def gptq_gemm(a: torch.Tensor, packed: PackedW4, c: torch.Tensor,
     if need:
         # deferred slabs live in their own buffer: attention split-KV scratch, other split-K GEMMs
         # and act-order copies (which all use the shared workspace) can never overwrite them
-        ws = _grow(_deferred_ws, need, a.device, "deferred split-K buffer") if deferred else \
-            reserve_workspace(need, a.device)
+        ws = _grow(_deferred_ws_b if slot else _deferred_ws, need, a.device,
+                   "deferred split-K buffer") if deferred else reserve_workspace(need, a.device)
         g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel()
-    check(L.slm_w4a16_gemm(C.byref(g), _stream()), "slm_w4a16_gemm")
+    if npro is not None:
+        check(L.slm_w4a16_gemv_norm(C.byref(g), C.byref(npro), _stream()), "slm_w4a16_gemv_norm")
+    else:
+        check(L.slm_w4a16_gemm(C.byref(g), _stream()), "slm_w4a16_gemm")
     if deferred:
         key = _dev_key(a.device)
-        gen = _deferred_gen.get(key, 0) + 1
-        _deferred_gen[key] = gen  # any older handle on this device is now stale
-        return DeferredPartials(g.workspace, deferred, g.M * g.N, key, gen, ws)
+        gen = _deferred_gen.get((key, slot), 0) + 1
+        _deferred_gen[(key, slot)] = gen  # any older handle on this buffer is now stale
+        return DeferredPartials(g.workspace, deferred, g.M * g.N, key, gen, ws, slot)
     return DeferredPartials()
 
 
@@ -470,11 +555,7 @@ def rms_norm(out: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, eps: floa
     if partials:
         if not isinstance(partials, DeferredPartials):
             raise SlmError("rms_norm(partials=...) takes the handle gptq_gemm(defer_reduce=True) returned")
-        if partials.key != _dev_key(x.device) or partials.numel != x.numel():
-            raise SlmError("rms_norm(partials=...): the handle belongs to another device or shape")
-        if _deferred_gen.get(partials.key) != partials.generation:
-            raise SlmError("rms_norm(partials=...): stale handle -- a later deferred GEMM on this "
-                           "device has overwritten the slabs")
+        partials.check(x.device, x.numel(), "rms_norm(partials=...)")
         check(L.slm_rms_norm_splitk(out.data_ptr(), partials.ptr, partials.splits, weight.data_ptr(),
                                     res_ptr, x.numel() // dim, dim, float(eps), _dtype_code(x),
                                     _stream()), "slm_rms_norm_splitk")
@@ -535,11 +616,7 @@ def apply_rotary_pos_emb(query: torch.Tensor, key: torch.Tensor, positions: torc
         if not isinstance(partials, DeferredPartials):
             raise SlmError("apply_rotary_pos_emb(partials=...) takes the handle gptq_gemm(defer_reduce=True) returned")
         n_cols = (query.size(1) + 2 * key.size(1)) * query.size(2)
-        if partials.key != _dev_key(query.device) or partials.numel != query.size(0) * n_cols:
-            raise SlmError("apply_rotary_pos_emb(partials=...): the handle belongs to another device or shape")
-        if _deferred_gen.get(partials.key) != partials.generation:
-            raise SlmError("apply_rotary_pos_emb(partials=...): stale handle -- a later deferred GEMM "
-                           "on this device has overwritten the slabs")
+        partials.check(query.device, query.size(0) * n_cols, "apply_rotary_pos_emb(partials=...)")
         if value is None or value.shape != key.shape or value.stride(-1) != 1 or \
                 value.stride(-2) != value.size(-1):
             raise SlmError("partials: value must be the [n_tokens, n_kv_heads, head_dim] slice of the qkv buffer")

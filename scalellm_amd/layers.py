@@ -197,21 +197,23 @@ class _QLinearBase:
         self._ckpt = {}
 
     def _gemm(self, x: torch.Tensor, bias: Optional[torch.Tensor],
-              out: Optional[torch.Tensor], defer_splitk: bool = False) -> torch.Tensor:
+              out: Optional[torch.Tensor], defer_splitk: bool = False,
+              norm: Optional[kernels.NormPrologue] = None) -> torch.Tensor:
         if self._packed is None:
             self._repack()
         x2 = x.reshape(-1, x.size(-1))
         if self.paired:
             if out is None:
                 out = torch.empty(x2.size(0), self._packed.N // 2, dtype=x.dtype, device=x.device)
-            kernels.gptq_gemm(x2, self._packed, out, bias, silu_mul=True)
+            kernels.gptq_gemm(x2, self._packed, out, bias, silu_mul=True, norm=norm)
             self.deferred, self.deferred_splits = kernels.DeferredPartials(), 0
             return out
         if out is None:
             out = torch.empty(x2.size(0), self._packed.N, dtype=x.dtype, device=x.device)
         # truthy: `out` was NOT written, fp32 split-K slabs wait in the deferred buffer for
         # kernels.rms_norm(..., partials=handle) (kernels.gptq_gemm, defer_reduce)
-        self.deferred = kernels.gptq_gemm(x2, self._packed, out, bias, defer_reduce=defer_splitk)
+        self.deferred = kernels.gptq_gemm(x2, self._packed, out, bias, defer_reduce=defer_splitk,
+                                          norm=norm)
         self.deferred_splits = int(self.deferred)
         return out
 
@@ -234,16 +236,31 @@ class ColumnParallelQLinear(_QLinearBase):
         if self.paired and gather_output:
             raise ValueError("act_mul needs the sharded output (gather_output=False)")
 
-    def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None,
-                defer_splitk: bool = False) -> torch.Tensor:
-        """defer_splitk (no bias, no gather, not act_mul): a split-K GEMM leaves its fp32 slabs for
-        the consumer (self.deferred is truthy then and `out` is NOT written) -- the fused qkv
-        projection hands them to the RoPE + append kernel (Attention.forward(qkv_partials=...))."""
+    def _defers(self, defer_splitk: bool) -> bool:
+        return defer_splitk and not self.has_bias and not self.paired and \
+            not (self.parallel_args.world_size > 1 and self.gather_output)
+
+    def norm_supported(self, n_tokens: int, defer_splitk: bool = False) -> bool:
+        """Can forward(..., norm=...) fold the preceding RMSNorm into this projection (M <= 4 GEMV)?"""
         if self._packed is None:
             self._repack()
-        defer = defer_splitk and not self.has_bias and not self.paired and \
-            not (self.parallel_args.world_size > 1 and self.gather_output)
-        y = self._gemm(x, self.bias if self.has_bias else None, out, defer_splitk=defer)
+        return kernels.gemv_norm_supported(n_tokens, self._packed, self.dtype, silu_mul=self.paired,
+                                           defer_reduce=self._defers(defer_splitk))
+
+    def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None,
+                defer_splitk: bool = False,
+                norm: Optional[kernels.NormPrologue] = None) -> torch.Tensor:
+        """defer_splitk (no bias, no gather, not act_mul): a split-K GEMM leaves its fp32 slabs for
+        the consumer (self.deferred is truthy then and `out` is NOT written) -- the fused qkv
+        projection hands them to the RoPE + append kernel (Attention.forward(qkv_partials=...)).
+
+        norm: `x` is the input of the RMSNorm that precedes this projection (input_layernorm_ /
+        post_attention_layernorm_, models/meta/llama.h:174-176), which then runs in the GEMV's
+        prologue (kernels.NormPrologue; only when norm_supported())."""
+        if self._packed is None:
+            self._repack()
+        defer = self._defers(defer_splitk)
+        y = self._gemm(x, self.bias if self.has_bias else None, out, defer_splitk=defer, norm=norm)
         if self.parallel_args.world_size > 1 and self.gather_output:
             y = gather_from_model_parallel_region(y, self.parallel_args)
         return y
