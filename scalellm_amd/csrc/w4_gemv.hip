@@ -43,7 +43,11 @@ struct GemvParams {
   int silu;      // SLM_W4_SILU_MUL: tw is even, tiles (2j, 2j+1) = (gate, up), c is [M, N/2]
 };
 
-constexpr int GV_RING = 8;  // weight ring depth (64-deep chunks per wave)
+// weight ring depth (64-deep chunks per wave).  Measured alternatives for the norm-prologue kernel
+// (Llama-3-8B bs=1 step, ring 8 issued first by every wave = 2.28 ms): ring 16 -> 2.36 ms (loads
+// return in order, so the prologue's own loads wait behind a twice as long burst); the four norm
+// waves issuing their ring only after row 0's loads landed -> 2.31 ms (their stream starts late).
+constexpr int GV_RING = 8;
 
 // NGC: scale groups per 64-deep chunk (2 for group 32, 1 otherwise); MT: token rows (1, 2, 4)
 // REFILL: the K slice of a wave is longer than the ring (otherwise every chunk is preloaded)
