@@ -179,7 +179,10 @@ __global__ void __launch_bounds__(256) rope_kv_append_kernel(
 // reads it there), k / v to `k` / `v` and to their cache slot.  A thread owns 4 + 4 values of one
 // head: dims [4u, 4u+4) and [half + 4u, ...) (non-interleaved pairs (i, i + half)) or the 8
 // consecutive dims [8u, 8u+8) (interleaved pairs (2i, 2i+1)): two 16-B loads per slab either way.
-template <typename T, typename CS>
+// PART = false: the same thread -> unit map over q / k / v as they are (slm_rope_kv_append with
+// 4-aligned layouts): in place, 8-byte loads, one round trip per thread where the scalar kernel
+// above makes one per rotation pair (Llama-3-8B, one token: 11 dependent trips, 5.3 us).
+template <typename T, typename CS, bool PART>
 __global__ void __launch_bounds__(256) rope_kv_append_splitk_kernel(
     const float* __restrict__ part, int n_splits, int64_t slab /* = n_tokens * N */, int64_t N,
     uint16_t* __restrict__ q, int64_t q_ts, uint16_t* __restrict__ k, int64_t k_ts,
@@ -198,11 +201,21 @@ __global__ void __launch_bounds__(256) rope_kv_append_splitk_kernel(
     else return lo_f32<T>((uint32_t)cs[i]);
   };
   const float* prow = part + tok * N;
+  const int64_t q_cols = (int64_t)n_heads * head_dim;
   // T(sum over slabs) of 4 consecutive columns, as fp32 values that are exact in T
+  // (column numbering of the fused GEMM row: [q | k | v])
   auto ld4 = [&](int64_t col, float (&x)[4]) {
-    const f32x4 s = splitk_sum4(prow + col, slab, n_splits);
-    x[0] = lo_f32<T>((uint32_t)pack1<T>(s.x)); x[1] = lo_f32<T>((uint32_t)pack1<T>(s.y));
-    x[2] = lo_f32<T>((uint32_t)pack1<T>(s.z)); x[3] = lo_f32<T>((uint32_t)pack1<T>(s.w));
+    if constexpr (PART) {
+      const f32x4 s = splitk_sum4(prow + col, slab, n_splits);
+      x[0] = lo_f32<T>((uint32_t)pack1<T>(s.x)); x[1] = lo_f32<T>((uint32_t)pack1<T>(s.y));
+      x[2] = lo_f32<T>((uint32_t)pack1<T>(s.z)); x[3] = lo_f32<T>((uint32_t)pack1<T>(s.w));
+    } else {
+      const uint16_t* src = col < q_cols ? q + tok * q_ts + col
+                            : col < q_cols + row ? k + tok * k_ts + (col - q_cols)
+                                                 : v + tok * v_ts + (col - q_cols - row);
+      const u32x2 w = *reinterpret_cast<const u32x2*>(src);
+      x[0] = lo_f32<T>(w.x); x[1] = hi_f32<T>(w.x); x[2] = lo_f32<T>(w.y); x[3] = hi_f32<T>(w.y);
+    }
   };
   auto st4 = [&](uint16_t* dst, const float (&x)[4]) {
     u32x2 w;
@@ -252,16 +265,18 @@ __global__ void __launch_bounds__(256) rope_kv_append_splitk_kernel(
     const int h = i / pass4, d = rot_dim + 4 * (i % pass4);
     const bool is_k = h >= n_heads;
     const int hh = is_k ? h - n_heads : h;
+    if (!PART && !(is_k && slot >= 0)) continue;  // in place: only the cache copy is left to do
     float x[4];
     ld4((int64_t)h * head_dim + d, x);
-    st4((is_k ? k + tok * k_ts : q + tok * q_ts) + (int64_t)hh * head_dim + d, x);
+    if constexpr (PART) st4((is_k ? k + tok * k_ts : q + tok * q_ts) + (int64_t)hh * head_dim + d, x);
     if (is_k && slot >= 0) st4(key_cache + slot * row + (int64_t)hh * head_dim + d, x);
   }
+  if (!PART && slot < 0) return;
   const int64_t v_col0 = (int64_t)n_rot_heads * head_dim;
   for (int i = t0; i < row / 4; i += tstep) {
     float x[4];
     ld4(v_col0 + 4 * i, x);
-    st4(v + tok * v_ts + 4 * i, x);
+    if constexpr (PART) st4(v + tok * v_ts + 4 * i, x);
     if (slot >= 0) st4(value_cache + slot * row + 4 * i, x);
   }
 }
@@ -349,6 +364,31 @@ SLM_API int slm_rope_kv_append(void* q, int64_t q_token_stride, void* k, int64_t
   if (dtype != SLM_F16 && dtype != SLM_BF16) return SLM_ERR_UNSUPPORTED;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   hip_clear_error();
+  // 4-aligned layouts (every model on the path): the vector kernel, one round trip per thread
+  const bool vec = cos_sin && rot_dim % 8 == 0 && head_dim % 4 == 0 && q_token_stride % 4 == 0 &&
+                   k_token_stride % 4 == 0 && (!slot_ids || v_token_stride % 4 == 0) &&
+                   !(reinterpret_cast<uintptr_t>(q) & 7) && !(reinterpret_cast<uintptr_t>(k) & 7) &&
+                   !(reinterpret_cast<uintptr_t>(v) & 7) && !(reinterpret_cast<uintptr_t>(key_cache) & 7) &&
+                   !(reinterpret_cast<uintptr_t>(value_cache) & 7);
+  if (vec) {
+    const int64_t units = ((int64_t)(n_heads + n_kv_heads) * (rot_dim / 8) + (int64_t)n_kv_heads * head_dim / 4);
+    const unsigned gy = units > 768 ? 4u : units > 256 ? 2u : 1u;
+    const dim3 vgrid((unsigned)n_tokens, gy), vblk(256);
+#define SLM_ROPE_V(TT, CST)                                                                     \
+  hipLaunchKernelGGL((rope_kv_append_splitk_kernel<TT, CST, false>), vgrid, vblk, 0, st,        \
+                     (const float*)nullptr, 0, (int64_t)0, (int64_t)0, (uint16_t*)q,            \
+                     q_token_stride, (uint16_t*)k, k_token_stride, (uint16_t*)const_cast<void*>(v), \
+                     v_token_stride, positions, (const CST*)cos_sin, rot_dim, interleaved,      \
+                     slot_ids, (uint16_t*)key_cache, (uint16_t*)value_cache, n_heads, n_kv_heads, \
+                     head_dim)
+    if (dtype == SLM_BF16) {
+      if (cos_sin_is_f32) SLM_ROPE_V(bf16_tag, float); else SLM_ROPE_V(bf16_tag, uint16_t);
+    } else {
+      if (cos_sin_is_f32) SLM_ROPE_V(f16_tag, float); else SLM_ROPE_V(f16_tag, uint16_t);
+    }
+#undef SLM_ROPE_V
+    return hip_check_launch();
+  }
   const dim3 grid((unsigned)n_tokens), blk(256);
 #define SLM_ROPE(TT, CST)                                                                       \
   hipLaunchKernelGGL((rope_kv_append_kernel<TT, CST>), grid, blk, 0, st, (uint16_t*)q,           \
@@ -394,7 +434,7 @@ SLM_API int slm_rope_kv_append_splitk(const float* partials, int32_t n_splits, v
   const unsigned gy = units > 768 ? 4u : units > 256 ? 2u : 1u;
   const dim3 grid((unsigned)n_tokens, gy), blk(256);
 #define SLM_ROPE_SK(TT, CST)                                                                     \
-  hipLaunchKernelGGL((rope_kv_append_splitk_kernel<TT, CST>), grid, blk, 0, st, partials, n_splits, \
+  hipLaunchKernelGGL((rope_kv_append_splitk_kernel<TT, CST, true>), grid, blk, 0, st, partials, n_splits, \
                      n_tokens * N, N, (uint16_t*)q, q_token_stride, (uint16_t*)k, k_token_stride, \
                      (uint16_t*)v, v_token_stride, positions, (const CST*)cos_sin, rot_dim,       \
                      interleaved, slot_ids, (uint16_t*)key_cache, (uint16_t*)value_cache, n_heads, \
