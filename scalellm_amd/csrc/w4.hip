@@ -761,9 +761,9 @@ static int gemm_impl(const slm_w4_gemm_args* a, const slm_w4_norm_prologue* np, 
   GemmPlan pl;
   int rc = plan_gemm(a, &pl);
   if (rc != SLM_OK) return rc;
+  if (a->M == 0) return SLM_OK;
   if (np && (!pl.gemv || a->perm || !gemv_supported(a->M, a->K, a->group_size, true)))
     return SLM_ERR_UNSUPPORTED;
-  if (a->M == 0) return SLM_OK;
   if ((!np && !a->a) || !a->wq || !a->sz || !a->c) return SLM_ERR_INVALID_ARG;
   const bool silu = (a->flags & SLM_W4_SILU_MUL) != 0;
   if (np) {

@@ -289,14 +289,76 @@ def test_product_path_never_imports_the_oracle():
                     "libslm_oracle" not in txt, f"{f} references the oracle"
 
 
+def test_gemv_norm_prologue_host_side():
+    """slm_w4a16_gemv_norm: whether a call is eligible is a pure function of the argument block
+    (and the tuning table), and every argument check returns before the first HIP call."""
+    from scalellm_amd._lib import W4NormPrologue
+    L = _lib.lib()
+    assert L.slm_tuning_clear(None) == 0
+    g = W4GemmArgs()
+    g.M, g.K, g.N, g.lda, g.ldc, g.group_size, g.dtype = 1, 4096, 6144, 4096, 6144, 128, 1
+    assert L.slm_w4a16_gemv_norm_supported(C.byref(g)) == 1          # the M = 1 GEMV
+    assert L.slm_w4a16_gemv_norm_supported(None) == 0
+    g.M = 2
+    assert L.slm_w4a16_gemv_norm_supported(C.byref(g)) == 0          # M = 2..4: MFMA kernel by default
+    assert L.slm_tuning_set(b"SLM_W4_GEMV", 2) == 0
+    try:
+        assert L.slm_w4a16_gemv_norm_supported(C.byref(g)) == 1      # ... on the GEMV with the knob
+        g.M = 5
+        assert L.slm_w4a16_gemv_norm_supported(C.byref(g)) == 0      # never above 4 rows
+        g.M, g.K, g.lda = 4, 16384, 16384                            # A (128 KiB) + the fp32 row > 160 KiB LDS
+        assert L.slm_w4a16_gemv_norm_supported(C.byref(g)) == 0
+        g.M = 1
+        assert L.slm_w4a16_gemv_norm_supported(C.byref(g)) == 1
+    finally:
+        assert L.slm_tuning_clear(b"SLM_W4_GEMV") == 0
+    g.M, g.K, g.lda = 1, 4096, 4096
+    g.perm = 4096                                                     # act-order: the gather is a separate launch
+    assert L.slm_w4a16_gemv_norm_supported(C.byref(g)) == 0
+    g.perm = None
+    g.flags, g.N, g.ldc = _lib.SLM_W4_SILU_MUL, 28672, 14336         # gate_up with the SiLU epilogue
+    assert L.slm_w4a16_gemv_norm_supported(C.byref(g)) == 1
+    g.flags, g.N, g.ldc = 0, 6144, 6144
+
+    g.wq, g.sz, g.c = 1 << 20, 2 << 20, 3 << 20                       # (never dereferenced: all calls fail first)
+    n = W4NormPrologue()
+    n.x, n.weight, n.eps = 4 << 20, 5 << 20, 1e-5
+    assert L.slm_w4a16_gemv_norm(None, C.byref(n), None) == -1
+    assert L.slm_w4a16_gemv_norm(C.byref(g), None, None) == -1
+    g.M = 8
+    assert L.slm_w4a16_gemv_norm(C.byref(g), C.byref(n), None) == -2  # not a GEMV shape
+    g.M = 1
+    n.weight = None
+    assert L.slm_w4a16_gemv_norm(C.byref(g), C.byref(n), None) == -1
+    n.weight, n.partials, n.n_splits = 5 << 20, 6 << 20, 2            # x AND partials
+    assert L.slm_w4a16_gemv_norm(C.byref(g), C.byref(n), None) == -1
+    n.x = None
+    n.n_splits = 0                                                    # partials without a slab count
+    assert L.slm_w4a16_gemv_norm(C.byref(g), C.byref(n), None) == -1
+    n.n_splits, n.residual_in = 2, 7 << 20                            # residual without a second buffer
+    assert L.slm_w4a16_gemv_norm(C.byref(g), C.byref(n), None) == -1
+    n.residual_out = 7 << 20                                          # ... or with the same one
+    assert L.slm_w4a16_gemv_norm(C.byref(g), C.byref(n), None) == -1
+    n.residual_out = (7 << 20) + 4096                                 # overlapping rows (8 KiB each)
+    assert L.slm_w4a16_gemv_norm(C.byref(g), C.byref(n), None) == -1
+    n.residual_out, n.normed_out = 8 << 20, 8 << 20                   # normed_out on top of residual_out
+    assert L.slm_w4a16_gemv_norm(C.byref(g), C.byref(n), None) == -1
+    n.normed_out = None
+    n.residual_out = (8 << 20) + 8                                    # alignment
+    assert L.slm_w4a16_gemv_norm(C.byref(g), C.byref(n), None) == -5
+    g.M = 0
+    assert L.slm_w4a16_gemv_norm(C.byref(g), C.byref(n), None) == 0   # empty batch
+
+
 def test_ctypes_structs_match_the_c_header(tmp_path):
     """ABI drift guard: size and every field offset of the ctypes mirrors (_lib.py) equal what a C
     compiler makes of include/slm_hip.h."""
     import shutil
     if shutil.which("gcc") is None:
         pytest.skip("no C compiler")
-    from scalellm_amd._lib import ArArgs, W4GemmArgs
-    structs = {"slm_attn_args": AttnArgs, "slm_w4_gemm_args": W4GemmArgs, "slm_ar_args": ArArgs}
+    from scalellm_amd._lib import ArArgs, W4GemmArgs, W4NormPrologue
+    structs = {"slm_attn_args": AttnArgs, "slm_w4_gemm_args": W4GemmArgs, "slm_ar_args": ArArgs,
+               "slm_w4_norm_prologue": W4NormPrologue}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "slm_hip.h"', 'int main(void) {']
     for cname, ct in structs.items():
         lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
