@@ -96,7 +96,27 @@ def measure_attention_kernel(model, tokens, positions, params, n_launch):
     return sum(times) / len(times), times[len(times) // 2]
 
 
-def measure_attention_traffic_live(bs, kv_len, n_heads, n_kv_heads, block):
+def _run_bounded(cmd, cwd, env, timeout_s):
+    """Run a profiler child without pipes (nothing for a lingering grandchild to hold open) in its
+    own session, and on timeout kill exactly that process group: a rocprofv3 that sits in its
+    teardown must cost this run `timeout_s`, not the driver's patience."""
+    import signal
+    import subprocess
+    with open(os.devnull, "w") as null:
+        p = subprocess.Popen(cmd, cwd=cwd, env=env, stdin=subprocess.DEVNULL, stdout=null, stderr=null,
+                             start_new_session=True)
+        try:
+            return p.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)  # the session we started: pgid == p.pid
+            except ProcessLookupError:
+                pass
+            p.wait()
+            raise
+
+
+def measure_attention_traffic_live(bs, kv_len, n_heads, n_kv_heads, block, timeout_s=120):
     """HBM bytes per paged-attention launch from the L2's memory-side counters, as
     MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE
     `rocprofv3 --pmc` passes (kernel-trace / stats only alongside), FETCH_SIZE x 2 on gfx950 (it
@@ -117,9 +137,8 @@ def measure_attention_traffic_live(bs, kv_len, n_heads, n_kv_heads, block):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="slm_pmc_", dir="/tmp")
         try:
-            r = subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
-                                sys.executable, tool], cwd="/tmp", env=env, capture_output=True, text=True,
-                               timeout=300)
+            rc = _run_bounded(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                               sys.executable, tool], cwd="/tmp", env=env, timeout_s=timeout_s)
             # one attention call = the stream kernel (token-major, or the MFMA tile form for wide GQA
             # groups) + the split-KV combine kernel when the call is split: all of them count
             total, n_main = 0.0, 0
@@ -134,8 +153,8 @@ def measure_attention_traffic_live(bs, kv_len, n_heads, n_kv_heads, block):
                             n_main += 1
                         elif "attn_combine_kernel" in name:
                             total += float(row["Counter_Value"])
-            if r.returncode != 0 or not n_main:
-                return None, f"rocprofv3 --pmc {counter} pass failed (rc {r.returncode})"
+            if rc != 0 or not n_main:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {rc})"
             vals[counter] = total / n_main
         except Exception as e:  # noqa: BLE001 -- the roofline line does not depend on the profiler
             return None, f"rocprofv3 --pmc {counter}: {type(e).__name__}"

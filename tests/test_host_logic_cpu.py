@@ -2,6 +2,7 @@
 reference's block-table / slot arithmetic (engine/batch.cpp:197-211, request/sequence.cpp:303-317)
 bit-exactly, and bench.py's algorithmic-byte model matches SURVEY 8d."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import oracle
@@ -86,3 +87,39 @@ def test_fused_allreduce_row_ownership():
             ar.rank = r
             seen += list(ar.owned_rows(M))
         assert seen == list(range(M))
+
+
+def test_bench_profiler_children_are_bounded(tmp_path, monkeypatch):
+    """bench.py's live-traffic measurement runs rocprofv3 twice as a child.  A profiler that sits in
+    its teardown (seen on this image) must cost the run a bounded time and leave nothing behind: the
+    child runs without pipes in its own session and the whole group is killed on timeout."""
+    import os
+    import subprocess
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    marker = tmp_path / "grandchild.pid"
+    t0 = time.time()
+    with pytest.raises(subprocess.TimeoutExpired):
+        bench._run_bounded(["sh", "-c", f"sleep 60 & echo $! > {marker}; sleep 60"], cwd=str(tmp_path),
+                           env=dict(os.environ), timeout_s=1.0)
+    assert time.time() - t0 < 10
+    pid = int(marker.read_text())
+    for _ in range(50):  # the grandchild went down with the group
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            break
+        time.sleep(0.1)
+    else:
+        pytest.fail("grandchild of the timed-out profiler is still alive")
+    assert bench._run_bounded(["sh", "-c", "exit 3"], cwd=str(tmp_path), env=dict(os.environ), timeout_s=5) == 3
+    # a hanging `rocprofv3` on PATH: the measurement gives up with a reason, the bench line goes on
+    fake = tmp_path / "rocprofv3"
+    fake.write_text("#!/bin/sh\nsleep 60\n")
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", f"{tmp_path}:{os.environ['PATH']}")
+    t0 = time.time()
+    traffic, why = bench.measure_attention_traffic_live(2, 64, 8, 2, 16, timeout_s=1.0)
+    assert traffic is None and "TimeoutExpired" in why and time.time() - t0 < 10
