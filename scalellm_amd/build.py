@@ -37,11 +37,23 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
+def _file_flags(src: str):
+    """Extra hipcc flags a source file asks for on a `// hipcc-flags: ...` line in its header."""
+    flags = []
+    with open(src) as f:
+        for i, line in enumerate(f):
+            if i > 80:
+                break
+            if line.startswith("// hipcc-flags:"):
+                flags += line.split(":", 1)[1].split()
+    return flags
+
+
 def _compile(src: str, force: bool) -> str:
     obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
     newest = max(os.path.getmtime(src), _deps_mtime())
     if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
-        cmd = [HIPCC, *CXXFLAGS, "-c", src, "-o", obj]
+        cmd = [HIPCC, *CXXFLAGS, *_file_flags(src), "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -29,6 +29,11 @@ enum TuneKey : int {
   TUNE_W4_PC,             // SLM_W4_PC
   TUNE_W4_SPLITK,         // SLM_W4_SPLITK         forced split-K
   TUNE_W4_POST,           // SLM_W4_POST
+  TUNE_W4_KS,             // SLM_W4_KS             0 = never use the K-sliced small-M kernel
+  TUNE_W4_KS_CW,          // SLM_W4_KS_CW          forced chunks of K per wave (1/2/4)
+  TUNE_W4_KS_NW,          // SLM_W4_KS_NW          forced waves per workgroup (4/8/16)
+  TUNE_W4_KS_TPW,         // SLM_W4_KS_TPW         forced column tiles per workgroup
+  TUNE_W4_KS_DBG,         // SLM_W4_KS_DBG         probe bits (1 = no activation loads, 2 = no weight loads): WRONG results
   TUNE_COUNT
 };
 

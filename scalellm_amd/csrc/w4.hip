@@ -500,6 +500,7 @@ __global__ void __launch_bounds__(256) w4_splitk_reduce_silu_kernel(
 // ------------------------------- host side ------------------------------------------
 struct GemmPlan {
   int mt, ntw, ng, pc, post, small, gemv, split_k, chunks_per_split, n_mblocks, n_nblocks;
+  int ks, ks_cw, ks_nw, ks_tpw;  // K-sliced small-M kernel (w4_ks.hip)
   size_t lds_bytes, part_bytes, aperm_bytes;
 };
 
@@ -607,6 +608,44 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
     pl->split_k = gemv_global_splits(a->M, a->K, a->N,
                                      (a->flags & SLM_W4_DEFER_REDUCE) && !a->bias && !a->perm);
     pl->chunks_per_split = n_chunks;
+  }
+  // M <= 32 (and M == 1 layers the GEMV cannot take): the K-sliced weight stream (w4_ks.hip) --
+  // K split over the waves of a workgroup (activations in registers), tiles reduced through LDS
+  pl->ks = 0;
+  const int ks_mode = tune_get(TUNE_W4_KS, 1);
+  if (ks_mode != 0 && a->M >= 1 && a->M <= 32 && !pl->gemv && pl->small &&
+      ((a->M - 1) * a->ldc + a->N) * 2 < ((int64_t)1 << 31) && a->M * a->N * 4 < ((int64_t)1 << 31)) {
+    const bool silu = (a->flags & SLM_W4_SILU_MUL) != 0;
+    const int n_tiles = (int)(a->N / 32);
+    int nw = tune_get(TUNE_W4_KS_NW, 0), cw = tune_get(TUNE_W4_KS_CW, 0), tpw = tune_get(TUNE_W4_KS_TPW, 0);
+    if (nw == 0) nw = 8;
+    if (cw == 0) {
+      const int cw_max = pl->ng == 4 ? 2 : 4;
+      if (silu) {  // the epilogue needs complete sums: one workgroup covers K
+        cw = 1;
+        while (cw < cw_max && nw * cw < n_chunks) cw *= 2;
+      } else {     // widest slice that still leaves a workgroup for (almost) every CU
+        cw = cw_max;
+        while (cw > 1 && (int64_t)((n_chunks + nw * cw - 1) / (nw * cw)) * n_tiles < 224) cw /= 2;
+      }
+    }
+    if (gemm_ks_config_ok(pl->ng, cw, nw)) {
+      const int ksplit = (n_chunks + nw * cw - 1) / (nw * cw);
+      if (tpw <= 0) {
+        tpw = (int)(((int64_t)ksplit * n_tiles + 128) / 256);
+        if (tpw < 1) tpw = 1;
+      }
+      if (silu) tpw = (tpw + 1) & ~1;
+      if (tpw > n_tiles) tpw = n_tiles;
+      if (!(silu && ksplit > 1) && ksplit <= 16) {
+        pl->ks = 1;
+        pl->ks_cw = cw; pl->ks_nw = nw; pl->ks_tpw = tpw;
+        pl->split_k = ksplit;
+        pl->chunks_per_split = nw * cw;
+        pl->n_mblocks = 1;
+        pl->n_nblocks = (n_tiles + tpw - 1) / tpw;
+      }
+    }
   }
   pl->part_bytes = pl->split_k > 1 ? (size_t)pl->split_k * a->M * a->N * sizeof(float) : 0;
   pl->aperm_bytes = a->perm ? (((size_t)a->M * a->K * 2 + 255) & ~(size_t)255) : 0;
@@ -824,7 +863,12 @@ static int gemm_impl(const slm_w4_gemm_args* a, const slm_w4_norm_prologue* np, 
   kp.split_k = pl.split_k; kp.chunks_per_split = pl.chunks_per_split;
   kp.n_mblocks = pl.n_mblocks; kp.n_nblocks = pl.n_nblocks;
   kp.silu = silu ? 1 : 0;
-  if (pl.gemv)
+  kp.ks_tpw = pl.ks ? pl.ks_tpw : 0;
+  kp.ks_groups = (int)(a->K / a->group_size);
+  kp.ks_dbg = tune_get(TUNE_W4_KS_DBG, 0);
+  if (pl.ks)
+    launch_gemm_ks(kp, a->dtype, pl.ng, pl.ks_cw, pl.ks_nw, pl.n_nblocks * pl.split_k, st);
+  else if (pl.gemv)
     launch_gemv(kp, a->dtype, pl.ng, st);
   else if (pl.small)
     launch_gemm_small(kp, a->dtype, pl.ng, pl.n_nblocks * pl.n_mblocks * pl.split_k, st);

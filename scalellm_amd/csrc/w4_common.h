@@ -89,6 +89,9 @@ struct GemmKParams {
   int chunks_per_split;
   int n_mblocks, n_nblocks;
   int silu;  // SLM_W4_SILU_MUL: column tiles are (gate, up) pairs, c is [M, N/2]
+  int ks_tpw;     // w4_ks.hip: consecutive column tiles per workgroup (n_nblocks = tile runs)
+  int ks_groups;  // w4_ks.hip: K / group_size (rows of the scale table)
+  int ks_dbg;     // w4_ks.hip: probe bits (SLM_W4_KS_DBG), 0 in production
   // GEMV norm prologue (slm_w4a16_gemv_norm): activations = rms_norm(x + residual_in) * weight,
   // computed in the kernel; norm_weight == NULL: none, `a` is read as usual
   const void* norm_x;          // [M, K] T or NULL
@@ -174,6 +177,13 @@ int gemv_global_splits(int64_t M, int64_t K, int64_t N, bool partials_ok);
 // lean weight-streaming kernel for M <= 32 (w4_small.hip): BM = 32, BN = 128, 256 threads
 void launch_gemm_small(const GemmKParams& kp, int dtype, int ng, int n_blocks, hipStream_t st);
 constexpr size_t W4_SMALL_LDS_BYTES = 2 * 32 * 256;
+
+// K-sliced weight stream for M <= 32 (w4_ks.hip): NW waves x CW chunks of K per workgroup, the
+// activations of a wave's K slice live in its registers, partial tiles meet in LDS once per tile
+void launch_gemm_ks(const GemmKParams& kp, int dtype, int ng, int cw, int nw, int n_blocks,
+                    hipStream_t st);
+bool gemm_ks_config_ok(int ng, int cw, int nw);
+constexpr size_t w4_ks_lds_bytes(int nw) { return (size_t)2 * nw * 4096; }
 
 // warp-specialised large-M kernel (w4_ws.hip): BM = 256, BN = 128, 512 threads
 void launch_gemm_ws(const GemmKParams& kp, int dtype, int ng, int n_blocks, hipStream_t st);

@@ -1,0 +1,448 @@
+// w4_ks.hip -- int4-weight x fp16/bf16-activation GEMM for M <= 32: the K-SLICED weight stream.
+//
+// Same operator as w4.hip (replaces marlin::gptq_gemm, reference gptq_gemm.cu:585-710, on the
+// small-batch decode shapes -- BASELINE configs[2]: Llama-3-8B AWQ, bs = 32), same packed layout
+// and scale/zero table (w4.hip header), same post-scaled numerics as w4_small.hip.
+//
+// What round 2 measured on w4_small.hip: one wave per SIMD walks a dependent chain
+// "activation fragment from LDS -> unpack -> MFMA -> group epilogue" with a workgroup barrier per
+// 128-deep chunk, 84 instructions per KiB of packed weights, 2.4 TB/s.  This kernel removes the
+// chain's shared parts instead of re-ordering them:
+//
+//  * K is split over the WAVES of a workgroup, and each wave keeps the activations of its K slice
+//    IN REGISTERS for the whole launch (CW chunks of 128 = 32 CW VGPRs in MFMA A-fragment form,
+//    loaded once, 16 B per lane per k-step straight from global memory).  The main loop therefore
+//    has no activation staging, no LDS fragment reads and no per-chunk barrier: per KiB of weights
+//    it issues one 16-B load, 28 unpack VALU, 4 MFMAs and 8 VALU of group epilogue.
+//  * a wave walks the column tiles of its workgroup one after the other; the NW partial 32 x 32
+//    tiles meet in LDS once per column tile (double-buffered: ONE barrier per tile) and every wave
+//    sums and stores 1/NW of the tile in a fixed order -- bit-reproducible, no global split-K and
+//    no reduce launch when NW * CW chunks cover K.
+//  * the zero-point term of the post-scaled form, sum_g X_g[m] * (-(magic + z_g[n]) s_g[n]), is a
+//    rank-(K/group) update: it runs on the matrix pipe as exact-fp32 MFMAs (v_mfma_f32_32x32x2_f32,
+//    two scale groups per instruction), with the activation group sums X_g taken ONCE per launch
+//    from the wave's own fragments (MFMA against a ones fragment: the result lands lane = token).
+//    w4_small.hip spent a second bf16 MFMA per k-step (half of its matrix-pipe time) on X.
+//  * weights: 8-slot register ring of 1-KiB half chunks (32 VGPRs), each slot refilled right after
+//    its last use with the half chunk 8 positions ahead; every VMEM operation is visible to the
+//    compiler, so the waits are exact counted vmcnt and stay in flight across the tile barrier.
+//
+// Launch shape (plan_gemm): grid = split_k x tile runs; workgroup = NW waves x CW chunks of K,
+// `ks_tpw` consecutive column tiles.
+//
+// Built without the SLP vectoriser: it packs the group epilogue into v_pk_fma_f32 and gathers the
+// packed tree at the END of a tile, which keeps every partial tile live (spills) and serialises the
+// epilogue behind the MFMAs; scalar v_fma_f32 hide under the matrix pipe (MI355X_MICROARCH: packed
+// fp32 VALU is an anti-lever beside MFMAs).
+// hipcc-flags: -fno-slp-vectorize
+#include "w4_common.h"
+
+namespace slm {
+
+template <typename T>
+struct KsOnes;
+template <>
+struct KsOnes<bf16_tag> {
+  static constexpr uint32_t bits = 0x3F803F80u;
+};
+template <>
+struct KsOnes<f16_tag> {
+  static constexpr uint32_t bits = 0x3C003C00u;
+};
+
+// raw buffer resources: SGPR base + 32-bit offsets (no 64-bit VALU address math per load), and
+// out-of-range stores are dropped by the hardware -- rows >= M and tiles past the run need no branch,
+// so the loop body is straight-line code and hipcc's vmcnt waits stay exact
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ks_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+constexpr uint32_t KS_OOB = 0x80000000u;  // beyond every resource here (all < 2 GiB or checked < 4 GiB)
+constexpr int KS_AUX_NT = 2;              // gfx940+ cache policy bits: sc0 = 1, nt = 2, sc1 = 16
+
+// CW: 128-deep chunks of K per wave (1, 2, 4);  NG: scale groups per chunk (1: group >= 128,
+// 2: 64, 4: 32);  NW: waves per workgroup (4, 8, 16)
+template <typename T, int CW, int NG, int NW, bool TL = false>
+__global__ void __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) w4a16_gemm_ks_kernel(const GemmKParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename Mfma<T>::frag frag_t;
+  constexpr int RS = NW == 16 ? 4 : 8;  // weight ring slots (1-KiB half chunks); 16 waves: 128-VGPR budget
+  constexpr int RD = RS / (2 * CW);     // column tiles per loop body (one ring turn)
+  constexpr int PP = NW == 16 ? 1 : 2;  // partial-sum tiles in flight (ping-pong under the epilogue)
+  constexpr int NGW = CW * NG;       // scale segments per wave and tile
+  constexpr int NP = (NGW + 1) / 2;  // segment pairs = fp32 MFMAs of the zero-point term
+  constexpr int WPG = 8 / NG;        // k-steps (weight words) per scale segment
+  constexpr int RPW = 16 / NW;       // accumulator registers a wave reduces and stores
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_tiles = (int)(p.N / 32);
+  const int run = (int)(blockIdx.x % (unsigned)p.n_nblocks);
+  const int ks = (int)(blockIdx.x / (unsigned)p.n_nblocks);
+  const int nt0 = run * p.ks_tpw;
+  const int ntl = min(p.ks_tpw, n_tiles - nt0);  // >= 1
+  const int cw0 = (ks * NW + wave) * CW;         // first chunk of this wave's K slice
+  const int clast = p.n_chunks - 1;
+  const bool kh = lane >= 32;
+  // TL (probe instantiation, SLM_W4_KS_DBG & 4): s_memtime stamps of every phase go to `c` instead of
+  // the result -- [workgroup][wave][32] u64, read by tools/probe_ks_timeline.py
+  auto stamp = [&](int idx) {
+    if constexpr (TL) {
+      const uint64_t tm = __builtin_amdgcn_s_memtime();
+      if (lane == 0 && idx < 32)
+        reinterpret_cast<uint64_t*>(p.c)[((int64_t)blockIdx.x * NW + wave) * 32 + idx] = tm;
+    }
+  };
+  stamp(0);
+
+  // ---- resources (the host checks the sizes: packed weights / scale table < 4 GiB, the rest < 2 GiB)
+  const __amdgpu_buffer_rsrc_t w_rs = ks_rsrc(p.wq, (uint32_t)((uint64_t)p.K * p.N / 2));
+  const __amdgpu_buffer_rsrc_t sz_rs = ks_rsrc(p.sz, (uint32_t)((uint64_t)p.ks_groups * p.N * 4));
+  const __amdgpu_buffer_rsrc_t a_rs = ks_rsrc(p.a, (uint32_t)(((p.M - 1) * p.lda + p.K) * 2));
+  const bool has_bias = p.bias != nullptr;
+  const __amdgpu_buffer_rsrc_t b_rs = ks_rsrc(has_bias ? p.bias : (const void*)p.sz, (uint32_t)(p.N * 2));
+  const bool final_out = p.split_k == 1;
+  const __amdgpu_buffer_rsrc_t c_rs =
+      ks_rsrc(p.c, final_out ? (uint32_t)(((p.M - 1) * p.ldc + (p.silu ? p.N / 2 : p.N)) * 2) : 0u);
+  const __amdgpu_buffer_rsrc_t part_rs =
+      ks_rsrc(final_out ? nullptr : p.part + (int64_t)ks * p.M * p.N, final_out ? 0u : (uint32_t)(p.M * p.N * 4));
+
+  const uint32_t w_voff = (uint32_t)lane * 16u;
+  const uint32_t sz_voff = (uint32_t)(lane & 31) * 4u;
+  const uint32_t b_voff = (uint32_t)(lane & 31) * 2u;
+  const uint32_t kt_stride = (uint32_t)n_tiles * 1024u;  // bytes per 64-deep kt
+  const uint32_t sz_stride = (uint32_t)p.N * 4u;         // bytes per scale group
+  const int cpg_shift = p.gs_shift >= 30 ? 30 : (p.gs_shift > 7 ? p.gs_shift - 7 : 0);
+  uint32_t woff[CW][2], soff[CW][NG];
+#pragma unroll
+  for (int c = 0; c < CW; ++c) {
+    const uint32_t cc = (uint32_t)min(cw0 + c, clast);  // chunks past K: clamped loads x zero activations
+#pragma unroll
+    for (int h = 0; h < 2; ++h) woff[c][h] = (cc * 2 + h) * kt_stride + (uint32_t)nt0 * 1024u;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const uint32_t grp = NG > 1 ? cc * NG + g : (cc >> cpg_shift);
+      soff[c][g] = grp * sz_stride + (uint32_t)nt0 * 128u;
+    }
+  }
+  const uint32_t w_dbg = (p.ks_dbg & 2) ? KS_OOB : 0u;  // probes: bit 0 = no activation loads, bit 1 = no weight loads
+  u32x4 ring[RD][CW][2];
+  uint32_t szr[RD][CW][NG];
+  uint32_t bsr[RD];
+  auto w_load = [&](int t, int c, int h) -> u32x4 {
+    const uint32_t tc = (uint32_t)min(t, ntl - 1);  // tiles past the run: clamped duplicates, never stored
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                         w_rs, (int)w_voff, (int)((woff[c][h] + tc * 1024u) | w_dbg), KS_AUX_NT));
+  };
+  auto sz_load = [&](int t, int c, int g) -> uint32_t {
+    const uint32_t tc = (uint32_t)min(t, ntl - 1);
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(sz_rs, (int)sz_voff, (int)(soff[c][g] + tc * 128u), 0);
+  };
+  auto b_load = [&](int t) -> uint32_t {
+    const uint32_t tc = (uint32_t)min(t, ntl - 1);
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(b_rs, (int)b_voff, (int)((uint32_t)(nt0 + tc) * 64u), 0);
+  };
+
+  // prologue, in the order the steady state issues (scales and bias of a tile, then its weights):
+  // the loop-carried vmcnt waits are merged with this path, so a different order here would make
+  // every wait in the loop conservative.  The ring goes first (HBM latency), the activations (L2)
+  // queue behind it.
+#pragma unroll
+  for (int d = 0; d < RD; ++d) {
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) szr[d][c][g] = sz_load(d, c, g);
+    }
+    bsr[d] = b_load(d);
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) ring[d][c][h] = w_load(d, c, h);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  stamp(1);
+
+  // ---- activations of this wave's K slice: A fragments (row = lane & 31, k = 16 j + 8 (lane >> 5) ..+7)
+  frag_t act[CW][8];
+  {
+    const int mrow = lane & 31;
+    const int mc = mrow < p.M ? mrow : (int)p.M - 1;  // rows >= M: clamped duplicates, never stored
+    const uint32_t a_voff = (uint32_t)(2 * (mc * p.lda + (kh ? 8 : 0)));
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const int cabs = cw0 + c;
+      // chunks past K: out-of-range loads return zero (zero activations x clamped weights = 0)
+      const uint32_t a_soff = (cabs <= clast && !(p.ks_dbg & 1)) ? (uint32_t)cabs * 256u : KS_OOB;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        act[c][j] = __builtin_bit_cast(
+            frag_t, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)(a_voff + j * 32), (int)a_soff, 0));
+    }
+  }
+
+  stamp(2);
+  // ---- activation sums per scale segment, lane = token: D = ones(32 x 16) . act^T -> every row of
+  // D holds X[m = lane & 31]; then the A operand of the fp32 MFMA (k = lane >> 5 picks the segment)
+  float xa[NP];
+  {
+    const u32x4 ones4 = {KsOnes<T>::bits, KsOnes<T>::bits, KsOnes<T>::bits, KsOnes<T>::bits};
+    const frag_t ones = __builtin_bit_cast(frag_t, ones4);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      float x2[2] = {0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int s = 2 * q + e;
+        if (s < NGW) {
+          const int c = s / NG, g = s % NG;
+          f32x16 t;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t[r] = 0.f;
+#pragma unroll
+          for (int jj = 0; jj < WPG; ++jj) t = Mfma<T>::run(ones, act[c][g * WPG + jj], t);
+          x2[e] = t[0];
+          __builtin_amdgcn_sched_barrier(0);  // one 16-register sum tile live at a time (register budget)
+        }
+      }
+      float x0 = x2[0], x1 = x2[1];
+      asm volatile("" : "+v"(x0), "+v"(x1));  // values, not array slots: keeps the select off the stack
+      xa[q] = kh ? x1 : x0;
+    }
+  }
+
+  if constexpr (TL) asm volatile("" : "+v"(xa[0]));
+  stamp(3);
+  uint32_t magic_v = W4Magic<T>::bits;
+  asm volatile("" : "+v"(magic_v));  // keep it in a VGPR (not re-materialised as a literal)
+  uint32_t mask_s = 0x000F000Fu;
+  asm volatile("" : "+s"(mask_s));   // ... and the nibble-pair mask in an SGPR (v_and_or_b32 takes no literal)
+
+  float* const red = reinterpret_cast<float*>(smem);
+  float hold[RPW];  // SLM_W4_SILU_MUL: the gate tile's values wait here for the up tile
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) hold[i] = 0.f;
+  const bool silu = p.silu != 0;
+  const uint32_t ldc2 = (uint32_t)p.ldc * 2u, n4 = (uint32_t)p.N * 4u;
+
+  const int n_iter = (ntl + RD - 1) / RD;  // >= 1
+  int it = 0;
+  do {  // do-while: with a guarded loop hipcc sinks the prologue loads behind the guard
+#pragma unroll
+    for (int d = 0; d < RD; ++d) {
+      const int t = it * RD + d;
+      stamp(4 + 4 * t);
+      // ---- scales of this tile (loaded one ring turn ago), then their registers take the loads for
+      // tile t + RD right away: issued BEFORE this tile's weight refills, so waiting for them at the
+      // start of tile t + RD leaves a full ring of weight loads in flight
+      float sc[NGW];
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        float cz2[2] = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int s = 2 * q + e;
+          if (s < NGW) {
+            float sv, zm;
+            W4Magic<T>::decode(szr[d][s / NG][s % NG], sv, zm);
+            sc[s] = sv;
+            cz2[e] = -zm * sv;  // <= 16 significant bits: exact
+          }
+        }
+        float c0 = cz2[0], c1 = cz2[1];
+        asm volatile("" : "+v"(c0), "+v"(c1));  // values, not array slots: keeps the select off the stack
+        // zero-point term on the matrix pipe (exact fp32): acc = sum_seg X_seg[m] * (-(magic+z) s)[n]
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[q], kh ? c1 : c0, acc, 0, 0, 0);
+      }
+      const uint32_t braw = bsr[d];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < CW; ++c) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) szr[d][c][g] = sz_load(t + RD, c, g);
+      }
+      bsr[d] = b_load(t + RD);
+      __builtin_amdgcn_sched_barrier(0);
+
+      // ---- the weight stream of this tile.  Segment s accumulates in tmp[s & 1] (PP = 2) while the
+      // scale epilogue of segment s - 1 runs under its MFMAs: exactly two partial tiles are live
+      f32x16 tmp[PP];
+#pragma unroll
+      for (int s = 0; s < NGW; ++s) {
+        const int c = s / NG, g = s % NG;
+#pragma unroll
+        for (int jj = 0; jj < WPG; ++jj) {
+          const int j = g * WPG + jj;
+          const u32x4 wv = ring[d][c][j >> 2];
+          const uint32_t word = (j & 3) == 0 ? wv.x : (j & 3) == 1 ? wv.y : (j & 3) == 2 ? wv.z : wv.w;
+          uint32_t o[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            // plain expression on opaque registers, NOT inline asm (hipcc inserts no hazard wait
+            // states behind an asm VALU feeding an MFMA: w4_small.hip)
+            const uint32_t x = q == 0 ? word : word >> (4 * q);
+            o[q] = (x & mask_s) | magic_v;
+          }
+          const u32x4 packed = {o[0], o[1], o[2], o[3]};
+          const frag_t bf = __builtin_bit_cast(frag_t, packed);
+          if (jj == 0) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            tmp[s % PP] = Mfma<T>::run(act[c][j], bf, z);
+          } else {
+            tmp[s % PP] = Mfma<T>::run(act[c][j], bf, tmp[s % PP]);
+          }
+          if (PP == 2 && s > 0 && jj == (WPG > 1 ? 1 : 0)) {
+            const float sv = sc[s - 1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaf(sv, tmp[(s - 1) % PP][r], acc[r]);
+            // pin the epilogue HERE (under this segment's MFMAs): without an anchor the scheduler
+            // sinks all of a tile's epilogues to the tile end and keeps every partial tile live.
+            // The anchor ties acc to the next weight word, so it can neither sink nor hoist.
+            if (jj + 1 < WPG || s + 1 < NGW) {
+              const int jn = jj + 1 < WPG ? j + 1 : ((s + 1) % NG) * WPG;
+              const int cn = jj + 1 < WPG ? c : (s + 1) / NG;
+              asm volatile("" : "+v"(acc), "+v"(ring[d][cn][jn >> 2]));
+            }
+          }
+          if ((j & 3) == 3) {  // last word of ring slot (c, j >> 2): refill it for tile t + RD
+            __builtin_amdgcn_sched_barrier(0);
+            ring[d][c][j >> 2] = w_load(t + RD, c, j >> 2);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (PP == 1 || s == NGW - 1) {
+          const float sv = sc[s];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = fmaf(sv, tmp[s % PP][r], acc[r]);
+        }
+      }
+
+      // ---- the NW partial tiles meet in LDS: [buffer][source wave][reducing wave][lane][RPW]
+      if constexpr (TL) {
+        asm volatile("" : "+v"(acc));  // the stamp follows the tile's last epilogue
+        stamp(5 + 4 * t);
+      }
+      const int buf = t & 1;
+      float* const mine = red + (buf * NW + wave) * 1024 + lane * RPW;
+#pragma unroll
+      for (int rg = 0; rg < NW; ++rg) {
+        if constexpr (RPW == 4) {
+          const f32x4 v = {acc[rg * 4], acc[rg * 4 + 1], acc[rg * 4 + 2], acc[rg * 4 + 3]};
+          *reinterpret_cast<f32x4*>(mine + rg * 256) = v;
+        } else if constexpr (RPW == 2) {
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          const f32x2 v = {acc[rg * 2], acc[rg * 2 + 1]};
+          *reinterpret_cast<f32x2*>(mine + rg * 128) = v;
+        } else {
+          mine[rg * 64] = acc[rg];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      stamp(6 + 4 * t);
+      float sum[RPW];
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) sum[i] = 0.f;
+      const float* const theirs = red + buf * NW * 1024 + (wave * 64 + lane) * RPW;
+#pragma unroll
+      for (int src = 0; src < NW; ++src) {
+        if constexpr (RPW == 4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(theirs + src * 1024);
+          sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+        } else if constexpr (RPW == 2) {
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          const f32x2 v = *reinterpret_cast<const f32x2*>(theirs + src * 1024);
+          sum[0] += v.x; sum[1] += v.y;
+        } else {
+          sum[0] += theirs[src * 1024];
+        }
+      }
+
+      // ---- store (straight-line: disabled stores go out of range and are dropped).  C/D layout of
+      // the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+      const int nt = nt0 + t;
+      const uint32_t col = (uint32_t)nt * 32u + (uint32_t)(lane & 31);
+      const uint32_t ocol = silu ? (uint32_t)(nt >> 1) * 32u + (uint32_t)(lane & 31) : col;
+      const bool tvalid = t < ntl;
+      const bool c_on = !TL && tvalid && final_out && (!silu || (t & 1));
+      const bool part_on = tvalid && !final_out;
+      const float bv = has_bias ? lo_f32<T>(braw) : 0.f;
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int r = wave * RPW + i;
+        const uint32_t row = (uint32_t)((r & 3) + 8 * (r >> 2)) + (kh ? 4u : 0u);
+        const float v = sum[i] + bv;
+        const float sm = silu_mul_acc<T>(hold[i], v);
+        hold[i] = v;
+        const uint16_t o16 = pack1<T>(silu ? sm : v);
+        __builtin_amdgcn_raw_buffer_store_b16(o16, c_rs, (int)(c_on ? row * ldc2 + ocol * 2u : KS_OOB), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, sum[i]), part_rs,
+                                              (int)(part_on ? row * n4 + col * 4u : KS_OOB), 0, 0);
+      }
+      if constexpr (TL) {
+        float keep = hold[0];
+        asm volatile("" : "+v"(keep));
+        stamp(7 + 4 * t);
+      }
+    }
+  } while (++it < n_iter);
+}
+
+template <typename T, int CW, int NG, int NW>
+static void launch_ks_t(const GemmKParams& kp, int n_blocks, hipStream_t st) {
+  hipLaunchKernelGGL((w4a16_gemm_ks_kernel<T, CW, NG, NW>), dim3((unsigned)n_blocks), dim3(NW * 64),
+                     w4_ks_lds_bytes(NW), st, kp);
+}
+
+template <typename T, int CW, int NG>
+static void launch_ks_nw(const GemmKParams& kp, int nw, int n_blocks, hipStream_t st) {
+  if (nw == 16) {
+    if constexpr (CW == 1) launch_ks_t<T, CW, NG, 16>(kp, n_blocks, st);  // 128-VGPR budget: one chunk
+  } else if (nw == 4) launch_ks_t<T, CW, NG, 4>(kp, n_blocks, st);
+  else launch_ks_t<T, CW, NG, 8>(kp, n_blocks, st);
+}
+
+template <typename T, int CW>
+static void launch_ks_ng(const GemmKParams& kp, int ng, int nw, int n_blocks, hipStream_t st) {
+  if (ng == 4) {
+    if constexpr (CW <= 2) launch_ks_nw<T, CW, 4>(kp, nw, n_blocks, st);
+  } else if (ng == 2) launch_ks_nw<T, CW, 2>(kp, nw, n_blocks, st);
+  else launch_ks_nw<T, CW, 1>(kp, nw, n_blocks, st);
+}
+
+template <typename T>
+static void launch_ks_cw(const GemmKParams& kp, int ng, int cw, int nw, int n_blocks, hipStream_t st) {
+  if (cw == 4) launch_ks_ng<T, 4>(kp, ng, nw, n_blocks, st);
+  else if (cw == 2) launch_ks_ng<T, 2>(kp, ng, nw, n_blocks, st);
+  else launch_ks_ng<T, 1>(kp, ng, nw, n_blocks, st);
+}
+
+bool gemm_ks_config_ok(int ng, int cw, int nw) {
+  if (cw != 1 && cw != 2 && cw != 4) return false;
+  if (nw != 4 && nw != 8 && nw != 16) return false;
+  if (nw == 16 && cw != 1) return false;
+  if (ng == 4 && cw == 4) return false;  // 16 segments per wave: register budget
+  return ng == 1 || ng == 2 || ng == 4;
+}
+
+void launch_gemm_ks(const GemmKParams& kp, int dtype, int ng, int cw, int nw, int n_blocks,
+                    hipStream_t st) {
+  if ((kp.ks_dbg & 4) && dtype == SLM_BF16 && ng == 1 && nw == 8 && (cw == 4 || cw == 2)) {  // timeline probe
+    if (cw == 4)
+      hipLaunchKernelGGL((w4a16_gemm_ks_kernel<bf16_tag, 4, 1, 8, true>), dim3((unsigned)n_blocks), dim3(512),
+                         w4_ks_lds_bytes(8), st, kp);
+    else
+      hipLaunchKernelGGL((w4a16_gemm_ks_kernel<bf16_tag, 2, 1, 8, true>), dim3((unsigned)n_blocks), dim3(512),
+                         w4_ks_lds_bytes(8), st, kp);
+    return;
+  }
+  if (dtype == SLM_BF16) launch_ks_cw<bf16_tag>(kp, ng, cw, nw, n_blocks, st);
+  else launch_ks_cw<f16_tag>(kp, ng, cw, nw, n_blocks, st);
+}
+
+}  // namespace slm
