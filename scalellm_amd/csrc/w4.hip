@@ -609,35 +609,44 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
                                      (a->flags & SLM_W4_DEFER_REDUCE) && !a->bias && !a->perm);
     pl->chunks_per_split = n_chunks;
   }
-  // M <= 32 (and M == 1 layers the GEMV cannot take): the K-sliced weight stream (w4_ks.hip) --
-  // K split over the waves of a workgroup (activations in registers), tiles reduced through LDS
+  // M <= 32 (M == 1 stays on the GEMV): the K-sliced weight stream (w4_ks.hip) -- K split over the
+  // waves of a workgroup (activations in registers), partial tiles reduced through LDS.  Launch
+  // shape from tools/bench_small_gemm.py sweeps on MI355X (profiles/r03_ks_sweep_m32.jsonl): the
+  // widest K slice per wave wins on every layer shape (fewest workgroups re-reading the
+  // activations), tiles per workgroup = about one workgroup per CU.  The slice width depends on K
+  // only -- NOT on the epilogue flags -- so that a fused SiLU*mul call and the plain call sum in the
+  // same order (bit-identical results, tests/test_w4_silu_gpu.py).
   pl->ks = 0;
-  const int ks_mode = tune_get(TUNE_W4_KS, 1);
-  if (ks_mode != 0 && a->M >= 1 && a->M <= 32 && !pl->gemv && pl->small &&
+  if (tune_get(TUNE_W4_KS, 1) != 0 && a->M >= 1 && a->M <= 32 && !pl->gemv && pl->small &&
       ((a->M - 1) * a->ldc + a->N) * 2 < ((int64_t)1 << 31) && a->M * a->N * 4 < ((int64_t)1 << 31)) {
     const bool silu = (a->flags & SLM_W4_SILU_MUL) != 0;
     const int n_tiles = (int)(a->N / 32);
+    const int cw_max = pl->ng == 4 ? 2 : 4;
     int nw = tune_get(TUNE_W4_KS_NW, 0), cw = tune_get(TUNE_W4_KS_CW, 0), tpw = tune_get(TUNE_W4_KS_TPW, 0);
-    if (nw == 0) nw = 8;
-    if (cw == 0) {
-      const int cw_max = pl->ng == 4 ? 2 : 4;
-      if (silu) {  // the epilogue needs complete sums: one workgroup covers K
+    const int forced_split = tune_get(TUNE_W4_SPLITK, 0);
+    if (nw == 0 && cw == 0 && forced_split > 0) {  // tests / sweeps that pin the split: honour it or step aside
+      for (int tw = 8; tw >= 4 && !nw; tw -= 4)
+        for (int tc = cw_max; tc >= 1 && !nw; tc >>= 1)
+          if ((n_chunks + tw * tc - 1) / (tw * tc) == forced_split && gemm_ks_config_ok(pl->ng, tc, tw)) {
+            nw = tw;
+            cw = tc;
+          }
+    } else {
+      if (nw == 0) nw = n_chunks <= 4 ? 4 : 8;
+      if (cw == 0) {
         cw = 1;
         while (cw < cw_max && nw * cw < n_chunks) cw *= 2;
-      } else {     // widest slice that still leaves a workgroup for (almost) every CU
-        cw = cw_max;
-        while (cw > 1 && (int64_t)((n_chunks + nw * cw - 1) / (nw * cw)) * n_tiles < 224) cw /= 2;
       }
     }
-    if (gemm_ks_config_ok(pl->ng, cw, nw)) {
+    if (nw && cw && gemm_ks_config_ok(pl->ng, cw, nw)) {
       const int ksplit = (n_chunks + nw * cw - 1) / (nw * cw);
       if (tpw <= 0) {
         tpw = (int)(((int64_t)ksplit * n_tiles + 128) / 256);
         if (tpw < 1) tpw = 1;
       }
-      if (silu) tpw = (tpw + 1) & ~1;
+      if (silu) tpw = (tpw + 1) & ~1;  // (gate, up) tile pairs stay in one workgroup
       if (tpw > n_tiles) tpw = n_tiles;
-      if (!(silu && ksplit > 1) && ksplit <= 16) {
+      if (ksplit <= 16 && (forced_split <= 0 || ksplit == forced_split)) {
         pl->ks = 1;
         pl->ks_cw = cw; pl->ks_nw = nw; pl->ks_tpw = tpw;
         pl->split_k = ksplit;

@@ -183,7 +183,7 @@ constexpr size_t W4_SMALL_LDS_BYTES = 2 * 32 * 256;
 void launch_gemm_ks(const GemmKParams& kp, int dtype, int ng, int cw, int nw, int n_blocks,
                     hipStream_t st);
 bool gemm_ks_config_ok(int ng, int cw, int nw);
-constexpr size_t w4_ks_lds_bytes(int nw) { return (size_t)2 * nw * 4096; }
+constexpr size_t w4_ks_lds_bytes(int nw) { return (size_t)4 * nw * 4096 + 64; }  // 4 partial slots + counters
 
 // warp-specialised large-M kernel (w4_ws.hip): BM = 256, BN = 128, 512 threads
 void launch_gemm_ws(const GemmKParams& kp, int dtype, int ng, int n_blocks, hipStream_t st);

@@ -258,14 +258,61 @@ def test_dot2_gemv_kernel_grid(bits, tune):
         assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, err)
 
 
+@pytest.mark.parametrize("bits", ["bf16", "f16"])
+def test_k_sliced_small_m_kernel_grid(bits):
+    """The K-sliced weight stream for M <= 32 (w4_ks.hip; default for 2 <= M <= 32): every slice width
+    (1 / 2 / 4 chunks per wave) x workgroup size (4 / 8 waves) x tiles per workgroup, every group size
+    incl. per-channel and groups wider than a wave's slice, K that does not fill the last workgroup's
+    waves (zero activations x clamped weights), tile runs that do not divide N (clamped duplicate
+    tiles, stores dropped), K split across workgroups (fp32 slabs + reduce), both formats, act-order,
+    bias, rows beyond M never stored."""
+    from scalellm_amd import kernels
+    i = 0
+    for M, N, K, gs, fmt, act, knobs in (
+            (32, 4096, 4096, 128, "awq", False, {}),                                   # auto: 8 x 4, one tile
+            (32, 1024, 4096, 128, "awq", False, dict(SLM_W4_KS_TPW=3)),                # ragged tile runs
+            (17, 512, 2048, 128, "gptq", False, dict(SLM_W4_KS_CW=1)),                 # 2 workgroups over K
+            (5, 288, 1152, 64, "gptq", True, dict(SLM_W4_KS_CW=2, SLM_W4_KS_NW=4)),    # 9 chunks on 4 x 2
+            (32, 160, 640, 32, "gptq", False, dict(SLM_W4_KS_CW=2)),                   # group 32, idle waves
+            (8, 384, 2048, -1, "gptq", False, dict(SLM_W4_KS_CW=4, SLM_W4_KS_NW=4)),   # per-channel
+            (2, 224, 1792, 256, "gptq", False, dict(SLM_W4_KS_CW=1, SLM_W4_KS_TPW=2)), # group > slice
+            (31, 256, 14336, 128, "awq", False, {}),                                   # 112 chunks: 4 x (8 x 4)
+            (32, 2048, 1024, 128, "awq", False, dict(SLM_W4_KS_NW=4, SLM_W4_KS_CW=2, SLM_W4_KS_TPW=5)),
+            (24, 96, 512, 128, "awq", False, {}),                                      # 4 chunks: 4-wave workgroup
+            (32, 6144, 4096, 128, "gptq", True, {})):
+        i += 1
+        case = helpers.make_quant_case(1700 + i, K, N, gs, fmt, bits, act_order=act)
+        with kernels.tuning(SLM_W4_KS=1, **knobs):  # per case: knobs of one case must not leak into the next
+            out, ref = _run_gemm(case, bits, M, bias=(i % 2 == 1), seed=i)
+        err = _rel_err(out, ref)
+        assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, knobs, err)
+
+
+@pytest.mark.parametrize("bits", ["bf16", "f16"])
+def test_lean_small_m_kernel_still_covered(bits, tune):
+    """w4_small.hip stays in the library for shapes the K-sliced kernel steps aside from (forced
+    split-K counts it cannot realise, SLM_W4_KS=0): keep its grid alive."""
+    tune(SLM_W4_KS=0)
+    i = 0
+    for M, N, K, gs, fmt, act in ((32, 4096, 4096, 128, "awq", False), (17, 512, 2048, 64, "gptq", False),
+                                  (8, 384, 2048, -1, "gptq", True), (2, 160, 640, 32, "gptq", False)):
+        i += 1
+        case = helpers.make_quant_case(1800 + i, K, N, gs, fmt, bits, act_order=act)
+        out, ref = _run_gemm(case, bits, M, bias=(i % 2 == 0), seed=i)
+        err = _rel_err(out, ref)
+        assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, err)
+
+
 @pytest.mark.parametrize("M,K,N,env", [(256, 2048, 28672, {"SLM_W4_MT": 8}),
                                        (384, 4096, 4096, {"SLM_W4_MT": 8, "SLM_W4_SPLITK": 4}),
                                        (512, 2048, 8192, {"SLM_W4_MT": 16}),
-                                       (32, 4096, 6144, {}), (1, 4096, 6144, {})])
+                                       (32, 4096, 6144, {}), (1, 4096, 6144, {}),
+                                       (32, 4096, 28672, {}), (32, 14336, 4096, {}),
+                                       (32, 4096, 6144, {"SLM_W4_KS": 0})])
 def test_repeated_launches_are_bit_identical(M, K, N, env, tune):
     """The wave-specialised / 256x256 / small-M / GEMV kernels synchronise with bare s_barriers,
-    counted vmcnt/lgkmcnt waits and LDS rings: a protocol error would show up as run-to-run
-    differences.  30 back-to-back launches (no host sync in between) must agree bit for bit."""
+    counted vmcnt/lgkmcnt waits and LDS rings, the K-sliced kernel with LDS arrival counters and a
+    four-slot partial ring: a protocol error would show up as run-to-run differences.  30 back-to-back launches (no host sync in between) must agree bit for bit."""
     from scalellm_amd import kernels
     tune(**env)
     case = helpers.make_quant_case(M + K + N, K, N, 128, "awq", "bf16")
