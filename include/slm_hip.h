@@ -116,6 +116,10 @@ typedef struct slm_attn_args {
 SLM_API size_t slm_paged_kv_varlen_mha_workspace_bytes(const slm_attn_args* a);
 /* Split count the heuristic would pick for `a` (host-side sizes only).        */
 SLM_API int32_t slm_paged_kv_varlen_mha_auto_splits(const slm_attn_args* a);
+/* which kernel the plan gives the q_len = 1 (decode) rows of this call: 0 = attn_token_kernel (HBM
+ * stream, dot2), 1 = attn_tile_kernel (MFMA tile form: wide GQA groups), -1 = invalid arguments.
+ * A pure function of the argument block and the tuning table (what a bench labels its roofline with). */
+SLM_API int32_t slm_paged_kv_varlen_mha_decode_kernel(const slm_attn_args* a);
 SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream);
 
 /* ========================================================================== */
@@ -157,6 +161,13 @@ SLM_API int slm_set_kv_cache(const int32_t* slot_ids,  /* [n_tokens]           *
 /*      sz  [G][N] {scale, magic + zero} as 2 x T (magic = 128 for bf16,      */
 /*           1024 for fp16: the sum is exact in T; fused scale/zero table);   */
 /*      perm[K] int32 (act-order only): row k' of wq = checkpoint row perm[k']*/
+/*           perm[k'] < 0 marks a PADDING row (weights 0, activation column   */
+/*           gathered as +0.0): a row-parallel act-order shard               */
+/*           (qlinear_gptq_marlin_impl.cpp:236-243: sharded g_idx, full       */
+/*           scales) holds an uneven number of rows of every group, so the    */
+/*           host pads each group's sorted rows to a multiple of 32 and packs */
+/*           with K = the padded row count, group_size = 32 and one scale row */
+/*           per 32-row block (tools: kernels.gptq_repack / slm::W4Linear).   */
 /* ========================================================================== */
 typedef enum slm_w4_format { SLM_W4_GPTQ = 0, SLM_W4_AWQ = 1 } slm_w4_format;
 #define SLM_W4_FORMAT_MASK 0xF
@@ -204,10 +215,10 @@ typedef struct slm_w4_gemm_args {
   const void* a;        /* [M, K] T, row stride lda (elements)                */
   const void* wq;       /* packed by slm_w4_prepack                           */
   const void* sz;       /* packed scale/zero table                            */
-  const int32_t* perm;  /* [K] act-order column gather for A, or NULL         */
+  const int32_t* perm;  /* [K] act-order column gather for A (entries < lda; < 0 = zero column), or NULL */
   const void* bias;     /* [N] T or NULL (added after accumulation)           */
   void* c;              /* [M, N] T, row stride ldc                           */
-  int64_t M, K, N;
+  int64_t M, K, N;      /* K = packed rows; with perm, A may be narrower (padded act-order shard) */
   int64_t lda, ldc;
   int64_t group_size;   /* K for per-channel (-1 in the checkpoint)           */
   int32_t dtype;

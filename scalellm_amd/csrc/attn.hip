@@ -669,6 +669,12 @@ SLM_API int32_t slm_paged_kv_varlen_mha_auto_splits(const slm_attn_args* a) {
   return pl.n_splits;
 }
 
+SLM_API int32_t slm_paged_kv_varlen_mha_decode_kernel(const slm_attn_args* a) {
+  AttnPlan pl;
+  if (plan_attn(a, &pl) != SLM_OK) return -1;
+  return decode_on_tile(a) ? 1 : 0;
+}
+
 SLM_API size_t slm_paged_kv_varlen_mha_workspace_bytes(const slm_attn_args* a) {
   AttnPlan pl;
   if (plan_attn(a, &pl) != SLM_OK) return 0;

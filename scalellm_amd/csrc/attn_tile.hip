@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
   const int rows_total = q_len * G;
   const int rows_per_wg = 32 * (nthreads >> 6);
   const int row0 = tile * rows_per_wg;
-  if (row0 >= rows_total || kv_len <= 0) return;  // workgroup-uniform
+  if (row0 >= rows_total) return;  // workgroup-uniform
   if (rows_total < p.rows_lo || rows_total >= p.rows_hi) return;  // another launch owns this sequence
 
   // this lane's query row
@@ -121,6 +121,25 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
   const int tq = jvalid ? jrow / G : (rows_total - 1) / G;  // token index inside the sequence
   const int head = kvh * G + (jvalid ? jrow % G : 0);
   const int diag = kv_len - q_len + tq;  // last visible kv index of this row (causal)
+  if (kv_len <= 0) {
+    // empty history (workgroup-uniform): this kernel owns the rows, so it publishes the empty
+    // result -- a zero output row, or a zero-weight partial (l = 0, O = 0) for the combine kernel,
+    // whose loads are unconditional (an unwritten partial would be combined as garbage)
+    if (!jvalid) return;
+    if (p.n_splits > 1) {
+      const int64_t pi = ((int64_t)(q_start + tq) * p.n_heads + head) * p.n_splits + split;
+      float* opp = p.o_part + pi * HD;
+      for (int d = 4 * hh; d < HD; d += 8) *reinterpret_cast<f32x4*>(opp + d) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (hh == 0) {
+        p.ml_part[pi * 2 + 0] = ATTN_M_INIT;
+        p.ml_part[pi * 2 + 1] = 0.f;
+      }
+    } else {
+      char* op = reinterpret_cast<char*>(p.out) + 2 * ((int64_t)(q_start + tq) * p.o_ts + (int64_t)head * p.o_hs);
+      for (int d = 4 * hh; d < HD; d += 8) *reinterpret_cast<u32x2*>(op + 2 * d) = u32x2{0u, 0u};
+    }
+    return;
+  }
 
   // Q fragments (B operand of S^T = K . Q^T): 8 consecutive dims per lane per k-step
   frag_t qf[KSTEPS];

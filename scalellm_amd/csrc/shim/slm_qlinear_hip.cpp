@@ -195,18 +195,19 @@ RowParallelQLinearHipImpl::RowParallelQLinearHipImpl(int64_t in_features, int64_
   TORCH_CHECK(local_out_ % 32 == 0 && local_in_ % 128 == 0, "int4 shapes: N % 32, K per rank % 128");
   if (quant_args.group_size() > 0)
     TORCH_CHECK(local_in_ % quant_args.group_size() == 0, "K per rank must hold whole scale groups");
-  // act-order rows of one K shard reference groups all over K (the reference then loads the FULL
-  // scales, qlinear_gptq_marlin_impl.cpp:236-243); the packed layout wants whole groups per shard
-  TORCH_CHECK(awq_ || !quant_args.desc_act() || world == 1,
-              "act-order GPTQ weights are not supported row-parallel with world_size > 1");
+  // act-order rows of one K shard reference groups all over K: like the reference
+  // (qlinear_gptq_marlin_impl.cpp:236-243 load_full_scales_) every rank then keeps the FULL scale /
+  // zero tables next to its rows and its slice of g_idx, and W4Linear packs the shard with padded
+  // groups (the HIP path's form of Marlin's is_k_full = false, :319)
+  full_scales_ = !awq_ && quant_args.desc_act() && world > 1;
 }
 
 void RowParallelQLinearHipImpl::load_state_dict(const StateDict& sd) {
   const bool grouped = quant_args_.group_size() > 0;
   load_one(sd, "qweight", 0, qweight_, qweight_is_loaded_);
   // per-channel scales (group_size -1) are one row: every rank keeps it whole
-  load_one(sd, "qzeros", grouped ? 0 : -1, qzeros_, qzeros_is_loaded_);
-  load_one(sd, "scales", grouped ? 0 : -1, scales_, scales_is_loaded_);
+  load_one(sd, "qzeros", grouped && !full_scales_ ? 0 : -1, qzeros_, qzeros_is_loaded_);
+  load_one(sd, "scales", grouped && !full_scales_ ? 0 : -1, scales_, scales_is_loaded_);
   if (!awq_ && quant_args_.desc_act()) load_one(sd, "g_idx", 0, g_idx_, g_idx_is_loaded_);
   if (has_bias_) load_one(sd, "bias", -1, bias_, bias_is_loaded_);  // added once, after the reduction
 }

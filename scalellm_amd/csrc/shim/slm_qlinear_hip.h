@@ -149,6 +149,7 @@ class RowParallelQLinearHipImpl : public QLinearHipBase {
 
  private:
   bool input_is_parallelized_;
+  bool full_scales_ = false;  // act-order shard: scales / qzeros loaded whole (load_full_scales_)
 };
 
 // parallel_linear.cpp:103-165: "gptq" / "awq" / "GEMM" (case-insensitive) -> the HIP impls

@@ -43,6 +43,7 @@ PYBIND11_MODULE(_slm_shim, m) {
         [](torch::Tensor out, torch::Tensor input) { llm::kernel::silu_and_mul(out, input); });
   m.def("silu_with_mul", &llm::kernel::silu_with_mul, py::arg("input"));
   // scalellm/csrc/kernels.cu:24-54, verbatim names and keyword arguments: `_C.kernels`
+  m.def("marlin_sz_cache_entries", &slm::marlin_sz_cache_entries);
   m.def("marlin_gemm",
         [](const torch::Tensor& A, const torch::Tensor& B, torch::Tensor C, const torch::Tensor& scales,
            const torch::Tensor& zeros, const torch::Tensor& g_idx, const torch::Tensor& perm,

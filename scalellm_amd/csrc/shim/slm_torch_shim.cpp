@@ -261,6 +261,26 @@ bool same_live_storage(const c10::weak_intrusive_ptr<c10::StorageImpl>& w, const
   return alive && alive.get() == t.storage().unsafeGetStorageImpl();
 }
 
+// is_k_full = false on a tensor that DOES hold whole groups (the reference's own test grid runs
+// that combination on full layers, marlin_gemm_test.py:52) is the same computation as is_k_full =
+// true; whether the SORTED g_idx the caller passes is the regular 0,0,..,1,1,.. pattern is decided
+// once per g_idx tensor (a device -> host comparison: first call = warm-up, never under capture).
+std::unordered_map<const void*, std::pair<c10::weak_intrusive_ptr<c10::StorageImpl>, bool>> g_gidx_cache;
+bool sorted_groups_are_whole(const torch::Tensor& g_idx, int64_t K, int64_t G) {
+  if (!g_idx.defined() || g_idx.numel() != K || G <= 0 || K % G) return false;
+  std::lock_guard<std::mutex> lk(g_sz_mu);
+  const auto it = g_gidx_cache.find(g_idx.const_data_ptr());
+  if (it != g_gidx_cache.end() && same_live_storage(it->second.first, g_idx)) return it->second.second;
+  for (auto e = g_gidx_cache.begin(); e != g_gidx_cache.end();)
+    e = e->second.first.expired() ? g_gidx_cache.erase(e) : std::next(e);
+  const auto trivial = torch::arange(K, torch::dtype(torch::kLong).device(g_idx.device())).floor_divide(K / G);
+  const bool whole = torch::equal(g_idx.to(torch::kLong), trivial);
+  g_gidx_cache.erase(g_idx.const_data_ptr());  // (weak pointers are not default-constructible: no operator[])
+  g_gidx_cache.emplace(g_idx.const_data_ptr(),
+                       std::make_pair(c10::weak_intrusive_ptr<c10::StorageImpl>(g_idx.storage().getWeakStorageImpl()), whole));
+  return whole;
+}
+
 void check_repack_args(const torch::Tensor& q_weight, const torch::Tensor& out, int64_t num_bits, int64_t K,
                        int64_t N) {
   TORCH_CHECK(num_bits == 4, "only 4-bit weights are supported on the HIP int4 path, got ", num_bits);
@@ -297,10 +317,18 @@ void awq_repack(const torch::Tensor& q_weight, torch::Tensor& out, int64_t num_b
 }
 
 void gptq_gemm(const torch::Tensor& A, const torch::Tensor& B, torch::Tensor& C,
-               const torch::Tensor& scales, const torch::Tensor& zeros, const torch::Tensor& /*g_idx*/,
-               const torch::Tensor& perm, torch::Tensor& /*workspace*/, int num_bits, bool /*is_k_full*/,
+               const torch::Tensor& scales, const torch::Tensor& zeros, const torch::Tensor& g_idx,
+               const torch::Tensor& perm, torch::Tensor& /*workspace*/, int num_bits, bool is_k_full,
                bool has_zp, bool /*use_fp32_reduce*/) {
   TORCH_CHECK(num_bits == 4, "only 4-bit weights are supported on the HIP int4 path, got ", num_bits);
+  // is_k_full = false is Marlin's mode for a row-parallel act-order shard: rows of one K shard belong
+  // to groups all over the FULL scale table, looked up through g_idx.  This function takes the
+  // packed weights at their checkpoint size, where that cannot be expressed; the layer classes
+  // (slm::RowParallelQLinearHipImpl -> slm::W4Linear) pack such a shard with padded groups instead.
+  if (!is_k_full && perm.defined() && perm.numel() > 0)
+    TORCH_CHECK(sorted_groups_are_whole(g_idx, A.size(1), scales.size(0)),
+                "marlin::gptq_gemm on the HIP path: is_k_full = false with uneven groups (a row-parallel "
+                "act-order shard) is handled by slm::RowParallelQLinearHipImpl, not by the raw kernel entry point");
   TORCH_CHECK(A.dim() == 2 && C.dim() == 2 && A.stride(1) == 1 && C.stride(1) == 1);
   const int64_t M = A.size(0), K = A.size(1), N = C.size(1);
   TORCH_CHECK(C.size(0) == M && B.numel() == K * N / 8 && B.scalar_type() == torch::kInt && B.is_contiguous(),
@@ -316,9 +344,11 @@ void gptq_gemm(const torch::Tensor& A, const torch::Tensor& B, torch::Tensor& C,
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(A.device());
   torch::Tensor sz;
   {
+    // _version() throws on inference-mode tensors (they carry no version counter and cannot be
+    // modified in place by autograd-visible ops): those count as version 0
+    const auto ver = [](const torch::Tensor& t) -> int64_t { return t.is_inference() ? 0 : static_cast<int64_t>(t._version()); };
     const SzKey key{scales.const_data_ptr(), zp ? zeros.const_data_ptr() : nullptr,
-                    static_cast<int64_t>(scales._version()) * 65537 + (zp ? static_cast<int64_t>(zeros._version()) : 0),
-                    K, N};
+                    ver(scales) * 65537 + (zp ? ver(zeros) : 0), K, N};
     std::lock_guard<std::mutex> lk(g_sz_mu);
     auto it = g_sz_cache.find(key);
     if (it != g_sz_cache.end() &&
@@ -327,6 +357,10 @@ void gptq_gemm(const torch::Tensor& A, const torch::Tensor& B, torch::Tensor& C,
       it = g_sz_cache.end();
     }
     if (it == g_sz_cache.end()) {
+      // a miss is rare (once per layer, during warm-up): sweep the entries whose parameters are gone
+      // (a model reload puts the layers at new addresses; their tables would otherwise live forever)
+      for (auto e = g_sz_cache.begin(); e != g_sz_cache.end();)
+        e = (e->second.scales_st.expired() || e->second.zeros_st.expired()) ? g_sz_cache.erase(e) : std::next(e);
       sz = torch::empty({G * N}, torch::dtype(torch::kInt).device(A.device()));
       check(slm_w4_prepack_sz(zp ? SLM_W4_AWQ : SLM_W4_GPTQ, zp ? zeros.const_data_ptr<int32_t>() : nullptr,
                               scales.const_data_ptr(), K, N, gs, dtype_code(scales), sz.mutable_data_ptr(),
@@ -366,6 +400,11 @@ void gptq_gemm(const torch::Tensor& A, const torch::Tensor& B, torch::Tensor& C,
 
 namespace slm {
 
+size_t marlin_sz_cache_entries() {
+  std::lock_guard<std::mutex> lk(marlin::g_sz_mu);
+  return marlin::g_sz_cache.size();
+}
+
 W4Linear::W4Linear(const std::string& quant_method, const torch::Tensor& qweight,
                    const torch::Tensor& qzeros, const torch::Tensor& scales,
                    const std::optional<torch::Tensor>& g_idx, int64_t group_size) {
@@ -383,11 +422,17 @@ W4Linear::W4Linear(const std::string& quant_method, const torch::Tensor& qweight
         torch::arange(K_, torch::dtype(torch::kLong).device(gi.device())).floor_divide(group_size_);
     if (!torch::equal(gi, trivial)) {
       const auto perm = torch::argsort(gi, /*stable=*/true, /*dim=*/0, /*descending=*/false);
-      TORCH_CHECK(torch::equal(gi.index({perm}), trivial),
-                  "act-order g_idx with uneven groups is not supported");
+      if (!torch::equal(gi.index({perm}), trivial)) {
+        // uneven groups after sorting: a row-parallel shard of an act-order checkpoint (sharded
+        // qweight / g_idx, FULL scales: qlinear_gptq_marlin_impl.cpp:236-243,270-276; the reference
+        // then runs Marlin with is_k_full = false, :319)
+        pack_uneven_groups(qweight, qzeros, scales, gi, perm);
+        return;
+      }
       perm_ = perm.to(torch::kInt).contiguous();
     }
   }
+  k_src_ = K_;
   const size_t wb = slm_w4_packed_weight_bytes(K_, N_);
   const size_t sb = slm_w4_packed_sz_bytes(K_, N_, group_size_);
   TORCH_CHECK(wb > 0 && sb > 0, "unsupported int4 shape K=", K_, " N=", N_, " group=", group_size_);
@@ -403,11 +448,56 @@ W4Linear::W4Linear(const std::string& quant_method, const torch::Tensor& qweight
         "slm_w4_prepack");
 }
 
+// Same plan as kernels.plan_uneven_groups (scalellm_amd/kernels.py): the sorted rows of every
+// group are padded to a multiple of 32 rows (padding rows: perm = -1, weights 0, activation column
+// gathered as +0.0), the total to a multiple of 128; every 32-row block then belongs to one group
+// and the kernels run it as group_size = 32 with one {scale, zero} row per block.
+void W4Linear::pack_uneven_groups(const torch::Tensor& qweight, const torch::Tensor& qzeros,
+                                  const torch::Tensor& scales, const torch::Tensor& gi,
+                                  const torch::Tensor& perm) {
+  constexpr int64_t B = 32;
+  const int64_t G = scales.size(0), gs = group_size_;
+  TORCH_CHECK(scales.dim() == 2 && scales.size(1) == N_ && qzeros.size(0) == G && qzeros.size(1) == N_ / 8,
+              "act-order shard: scales / qzeros must be the FULL tables [n_groups, N]");
+  TORCH_CHECK(gi.min().item<int64_t>() >= 0 && gi.max().item<int64_t>() < G,
+              "g_idx refers to a scale group the scales tensor does not have");
+  const auto lopt = torch::dtype(torch::kLong).device(gi.device());
+  const auto gs_sorted = gi.index({perm});
+  const auto counts = torch::bincount(gs_sorted, /*weights=*/{}, /*minlength=*/G);
+  const auto padded = (counts + (B - 1)).floor_divide(B) * B;
+  const auto starts = torch::cumsum(padded, 0) - padded;
+  const auto cstarts = torch::cumsum(counts, 0) - counts;
+  const auto pos = starts.index({gs_sorted}) + (torch::arange(K_, lopt) - cstarts.index({gs_sorted}));
+  const int64_t total = padded.sum().item<int64_t>();
+  const int64_t kp = (total + 127) / 128 * 128;
+  auto perm_p = torch::full({kp}, -1, torch::dtype(torch::kInt).device(gi.device()));
+  perm_p.index_put_({pos}, perm.to(torch::kInt));
+  auto block_group = torch::repeat_interleave(torch::arange(G, lopt), padded.floor_divide(B));
+  if (kp > total) block_group = torch::cat({block_group, torch::zeros({(kp - total) / B}, lopt)});
+  k_src_ = K_;
+  K_ = kp;
+  group_size_ = B;
+  perm_ = perm_p.contiguous();
+  const auto iopt = torch::dtype(torch::kInt).device(qweight.device());
+  const size_t wb = slm_w4_packed_weight_bytes(K_, N_);
+  TORCH_CHECK(wb > 0, "unsupported int4 shape K=", K_, " N=", N_);
+  wq_ = torch::empty({static_cast<int64_t>(wb / 4)}, iopt);
+  const auto qw = qweight.contiguous(), qz = qzeros.contiguous(), sc = scales.contiguous();
+  check(slm_w4_prepack_weights(SLM_W4_GPTQ, qw.const_data_ptr<int32_t>(), perm_.const_data_ptr<int32_t>(), K_, N_,
+                               wq_.mutable_data_ptr(), current_stream(qw)),
+        "slm_w4_prepack_weights");
+  auto sz_full = torch::empty({G, N_}, iopt);
+  check(slm_w4_prepack_sz(SLM_W4_GPTQ, qz.const_data_ptr<int32_t>(), sc.const_data_ptr(), G * gs, N_, gs,
+                          dtype_code(sc), sz_full.mutable_data_ptr(), current_stream(qw)),
+        "slm_w4_prepack_sz");
+  sz_ = sz_full.index({block_group}).contiguous().view({-1});
+}
+
 torch::Tensor W4Linear::forward(const torch::Tensor& input, const std::optional<torch::Tensor>& bias,
                                 std::optional<torch::Tensor> out) const {
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input.device());
   const auto a = input.reshape({-1, input.size(-1)});
-  TORCH_CHECK(a.size(1) == K_ && a.stride(1) == 1 && a.scalar_type() == dtype_);
+  TORCH_CHECK(a.size(1) == k_src_ && a.stride(1) == 1 && a.scalar_type() == dtype_);
   torch::Tensor c = out.has_value() ? *out : torch::empty({a.size(0), N_}, a.options());
   slm_w4_gemm_args g{};
   g.a = a.const_data_ptr();

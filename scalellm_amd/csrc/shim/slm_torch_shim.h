@@ -109,6 +109,10 @@ namespace slm {
 
 // int4 linear in the library's packed layout.  Built once from CHECKPOINT-format tensors (the
 // same tensors the reference's load_state_dict collects), then forward() = one GEMM launch.
+// entries of the fused {scale, zero} table cache behind marlin::gptq_gemm (tests: the cache is swept
+// of tables whose parameters were freed)
+size_t marlin_sz_cache_entries();
+
 class W4Linear {
  public:
   // quant_method "awq": qweight [K, N/8], qzeros [G, N/8] (AWQ interleave), scales [G, N]
@@ -122,12 +126,17 @@ class W4Linear {
                         std::optional<torch::Tensor> out = std::nullopt) const;
   torch::Tensor dequantize() const;  // dense [K, N] (debug / parity)
 
-  int64_t in_features() const { return K_; }
+  int64_t in_features() const { return k_src_; }
   int64_t out_features() const { return N_; }
 
  private:
+  // a row-parallel shard of an act-order checkpoint: g_idx [K] sharded, scales / qzeros the FULL
+  // tables (qlinear_gptq_marlin_impl.cpp:236-243) -> padded groups, packed K_ > k_src_
+  void pack_uneven_groups(const torch::Tensor& qweight, const torch::Tensor& qzeros, const torch::Tensor& scales,
+                          const torch::Tensor& gi, const torch::Tensor& perm);
   torch::Tensor wq_, sz_, perm_;
   int64_t K_ = 0, N_ = 0, group_size_ = 0;
+  int64_t k_src_ = 0;  // width of the activations (== K_ unless the shard was padded)
   torch::ScalarType dtype_;
 };
 

@@ -72,7 +72,9 @@ __global__ void __launch_bounds__(256) w4_prepack_weight_kernel(
   for (int e = 0; e < 8; ++e) {
     const int64_t k = perm ? (int64_t)perm[kb + e] : kb + e;
     uint32_t q;
-    if ((format & SLM_W4_FORMAT_MASK) == SLM_W4_GPTQ)
+    if (k < 0)  // padding row of an uneven act-order shard: its activation column is gathered as 0
+      q = 0u;
+    else if ((format & SLM_W4_FORMAT_MASK) == SLM_W4_GPTQ)
       q = (qweight[(k / 8) * N + n] >> (4 * (k % 8))) & 0xFu;
     else
       q = (qweight[k * (N / 8) + n / 8] >> (4 * awq_pos((int)(n % 8)))) & 0xFu;
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(256) w4_permute_cols_kernel(const uint16_t* __
   const int64_t m = blockIdx.y;
   for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < K;
        k += (int64_t)gridDim.x * blockDim.x)
-    out[m * K + k] = a[m * lda + perm[k]];
+    out[m * K + k] = perm[k] >= 0 ? a[m * lda + perm[k]] : (uint16_t)0;  // < 0: padding column (+0.0)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -834,7 +836,9 @@ static int gemm_impl(const slm_w4_gemm_args* a, const slm_w4_norm_prologue* np, 
         !aligned16(np->residual_out) || !aligned16(np->weight) || !aligned16(np->normed_out))
       return SLM_ERR_ALIGNMENT;
   }
-  if ((!np && (!aligned16(a->a) || a->lda % 8 || a->lda < a->K)) || !aligned16(a->wq) ||
+  // with perm the packed K may exceed the source width (padded act-order shards): perm[k] < lda is
+  // the caller's contract then
+  if ((!np && (!aligned16(a->a) || a->lda % 8 || (!a->perm && a->lda < a->K))) || !aligned16(a->wq) ||
       a->ldc < (silu ? a->N / 2 : a->N))
     return SLM_ERR_ALIGNMENT;
   if ((pl.part_bytes + pl.aperm_bytes) > 0 &&

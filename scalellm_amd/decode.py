@@ -52,10 +52,12 @@ class LlamaShape:
                           n_layers=2, vocab=1024, max_position=512)
 
 
-def _rand_int4_linear(gen, K, N, group_size, fmt, dtype, device, sym=False):
+def _rand_int4_linear(gen, K, N, group_size, fmt, dtype, device, sym=False, desc_act=False):
     """Random layer in CHECKPOINT format (AWQ [K,N/8] / GPTQ [K/8,N]); random bits = uniform nibbles.
     sym: GPTQ symmetric quantisation -- every stored zero point is 7 (zero = stored + 1 = 8,
-    qlinear_impl.cpp:45), what `sym: true` GPTQ checkpoints carry."""
+    qlinear_impl.cpp:45), what `sym: true` GPTQ checkpoints carry.
+    desc_act (GPTQ): an act-order checkpoint -- g_idx[k] = scale group of row k, a random
+    assignment with exactly group_size rows per group (what `desc_act: true` quantisation leaves)."""
     G = K // group_size
     if fmt == "awq":
         qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, (K, N // 8), device=device, generator=gen,
@@ -68,7 +70,13 @@ def _rand_int4_linear(gen, K, N, group_size, fmt, dtype, device, sym=False):
     if sym:
         qzeros.fill_(0x77777777)
     scales = (torch.rand(G, N, device=device, generator=gen) * 0.006 + 0.002).to(dtype)
-    return {"qweight": qweight, "qzeros": qzeros, "scales": scales}
+    ck = {"qweight": qweight, "qzeros": qzeros, "scales": scales}
+    if desc_act and fmt == "gptq":
+        order = torch.randperm(K, device=device, generator=gen)
+        g_idx = torch.empty(K, dtype=torch.int32, device=device)
+        g_idx[order] = (torch.arange(K, device=device) // group_size).to(torch.int32)
+        ck["g_idx"] = g_idx
+    return ck
 
 
 def _shard_cols(ck, fmt, col_ranges):
@@ -77,13 +85,21 @@ def _shard_cols(ck, fmt, col_ranges):
     (src/layers/linear/weight_utils.h:48-83, qkv_parallel_linear.cpp:20-60)."""
     def cat(t, div):
         return torch.cat([t[:, a // div:b // div] for a, b in col_ranges], dim=1).contiguous()
-    return {"qweight": cat(ck["qweight"], 8 if fmt == "awq" else 1), "qzeros": cat(ck["qzeros"], 8),
-            "scales": cat(ck["scales"], 1)}
+    out = {"qweight": cat(ck["qweight"], 8 if fmt == "awq" else 1), "qzeros": cat(ck["qzeros"], 8),
+           "scales": cat(ck["scales"], 1)}
+    if "g_idx" in ck:  # column-parallel: every rank holds all of K (qlinear_gptq_marlin_impl.cpp:150-165)
+        out["g_idx"] = ck["g_idx"]
+    return out
 
 
 def _shard_rows(ck, fmt, k0, k1, group_size):
-    """Row-parallel shard [k0, k1) of K (multiples of the group size)."""
+    """Row-parallel shard [k0, k1) of K (multiples of the group size).  Act-order checkpoints: the
+    rows of the shard belong to ANY group, so g_idx is sharded with the rows and the scale / zero
+    tables stay whole (qlinear_gptq_marlin_impl.cpp:236-243 load_full_scales_, :270-276)."""
     div = 1 if fmt == "awq" else 8
+    if "g_idx" in ck:
+        return {"qweight": ck["qweight"][k0 // div:k1 // div].contiguous(), "qzeros": ck["qzeros"],
+                "scales": ck["scales"], "g_idx": ck["g_idx"][k0:k1].contiguous()}
     return {"qweight": ck["qweight"][k0 // div:k1 // div].contiguous(),
             "qzeros": ck["qzeros"][k0 // group_size:k1 // group_size].contiguous(),
             "scales": ck["scales"][k0 // group_size:k1 // group_size].contiguous()}
@@ -94,7 +110,7 @@ class LlamaDecodeStep:
                  parallel_args: Optional[ParallelArgs] = None, quant_method: str = "awq",
                  group_size: int = 128, dtype=torch.bfloat16, device="cuda", seed: int = 0,
                  kv_fill: str = "none", custom_allreduce=None, keep_checkpoint: bool = False,
-                 gptq_sym: bool = False, fuse_silu: bool = True):
+                 gptq_sym: bool = False, fuse_silu: bool = True, desc_act: bool = False):
         pa = parallel_args or ParallelArgs()
         # fuse_silu: the merged gate_up weight is packed paired and SiLU*mul runs in the GEMM
         # epilogue (identical bits; False keeps the separate kernels.silu_and_mul launch)
@@ -121,8 +137,9 @@ class LlamaDecodeStep:
         # every rank draws the SAME full-size synthetic checkpoint (common seed) and keeps its
         # tensor-parallel shard, so TP=N and TP=1 are the same model (tests compare them)
         gen = torch.Generator(device=self.device).manual_seed(seed * 1000 + 17)
+        desc_act = desc_act and quant_method == "gptq"  # act-order GPTQ checkpoint (random g_idx)
         qa = QuantArgs(quant_method=quant_method, bits=4, group_size=group_size,
-                       zero_point=(quant_method == "awq"))
+                       zero_point=(quant_method == "awq"), desc_act=desc_act)
         inv_freq = 1.0 / (shape.rope_theta ** (torch.arange(0, D, 2, dtype=torch.float32,
                                                               device=self.device) / D))
         cos_sin = HipAttnHandler.build_cos_sin(D, shape.max_position, inv_freq)
@@ -141,22 +158,22 @@ class LlamaDecodeStep:
                                                  act_mul="silu" if fuse_silu else None)
             L["down"] = RowParallelQLinear(inter, H, False, qa, True, pa, dtype, self.device)
             full = _rand_int4_linear(gen, H, q_full + 2 * kv_full, group_size, quant_method, dtype, self.device,
-                                     sym=gptq_sym and quant_method == "gptq")
+                                     sym=gptq_sym and quant_method == "gptq", desc_act=desc_act)
             shard = {
                 "qkv": _shard_cols(full, quant_method, [
                     (r * nh * D, (r + 1) * nh * D),
                     (q_full + kv_head0 * D, q_full + (kv_head0 + nkv) * D),
                     (q_full + kv_full + kv_head0 * D, q_full + kv_full + (kv_head0 + nkv) * D)])}
             full = _rand_int4_linear(gen, q_full, H, group_size, quant_method, dtype, self.device,
-                                     sym=gptq_sym and quant_method == "gptq")
+                                     sym=gptq_sym and quant_method == "gptq", desc_act=desc_act)
             shard["o"] = _shard_rows(full, quant_method, r * nh * D, (r + 1) * nh * D, group_size)
             full = _rand_int4_linear(gen, H, 2 * inter, group_size, quant_method, dtype, self.device,
-                                     sym=gptq_sym and quant_method == "gptq")
+                                     sym=gptq_sym and quant_method == "gptq", desc_act=desc_act)
             shard["gate_up"] = _shard_cols(full, quant_method, [
                 (r * inter // tp, (r + 1) * inter // tp),
                 (inter + r * inter // tp, inter + (r + 1) * inter // tp)])
             full = _rand_int4_linear(gen, inter, H, group_size, quant_method, dtype, self.device,
-                                     sym=gptq_sym and quant_method == "gptq")
+                                     sym=gptq_sym and quant_method == "gptq", desc_act=desc_act)
             shard["down"] = _shard_rows(full, quant_method, r * inter // tp, (r + 1) * inter // tp, group_size)
             del full
             if keep_checkpoint:
@@ -217,7 +234,10 @@ class LlamaDecodeStep:
         s = self.shape
         need = n_tokens * self.n_heads * 256 * (s.head_dim + 2) * 4  # worst-case split-KV partials
         need = max(need, 64 * n_tokens * max(2 * s.intermediate // self.pa.world_size, s.hidden) * 4)
-        kernels.reserve_workspace(min(need, 4 << 30), self.device)
+        # deferred split-K slabs (o / down / qkv leave up to 16 fp32 slabs for their consumer): both slots
+        widest = max(s.hidden, (self.n_heads + 2 * self.n_kv_heads) * s.head_dim)
+        kernels.reserve_workspace(min(need, 4 << 30), self.device,
+                                  deferred_nbytes=16 * n_tokens * widest * 4)
 
     def forward(self, tokens: torch.Tensor, positions: torch.Tensor, params: InputParameters,
                 return_logits: bool = False) -> torch.Tensor:

@@ -116,9 +116,14 @@ def _grow(table, nbytes: int, dev: torch.device, what: str) -> torch.Tensor:
 
 def reserve_workspace(nbytes: int, device: Optional[torch.device] = None,
                       deferred_nbytes: int = 0) -> torch.Tensor:
+    """Size the per-device scratch once, before graph capture.  deferred_nbytes sizes BOTH deferred
+    split-K slab buffers (slot 0 and slot 1: a GEMM whose norm prologue consumes slot-0 slabs leaves
+    its own in slot 1), so a capture needs no warm-up of exactly that path and nothing is retired
+    later."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
     if deferred_nbytes:
         _grow(_deferred_ws, deferred_nbytes, dev, "deferred split-K buffer")
+        _grow(_deferred_ws_b, deferred_nbytes, dev, "deferred split-K buffer (slot 1)")
     return _grow(_workspaces, nbytes, dev, "workspace")
 
 
@@ -252,6 +257,23 @@ def paged_kv_varlen_mha_auto_splits(query, key_cache, q_cu_lens, block_size, max
     return int(_lib.lib().slm_paged_kv_varlen_mha_auto_splits(C.byref(a)))
 
 
+def paged_kv_varlen_mha_decode_kernel(n_tokens: int, batch_size: int, n_heads: int, n_kv_heads: int,
+                                      head_dim: int, block_size: int, max_q_len: int, max_kv_len: int,
+                                      dtype=torch.bfloat16, kv_slot_stride: Optional[int] = None) -> str:
+    """Name of the kernel the library's plan gives the q_len = 1 rows of such a call
+    (slm_paged_kv_varlen_mha_decode_kernel: current tuning table included; host-side only)."""
+    a = AttnArgs()
+    a.dtype = _lib.SLM_BF16 if dtype == torch.bfloat16 else _lib.SLM_F16
+    a.batch_size, a.n_tokens = int(batch_size), int(n_tokens)
+    a.n_heads, a.n_kv_heads, a.head_dim = int(n_heads), int(n_kv_heads), int(head_dim)
+    a.block_size, a.max_q_len, a.max_kv_len = int(block_size), int(max_q_len), int(max_kv_len)
+    a.k_stride[0] = a.v_stride[0] = int(kv_slot_stride or n_kv_heads * head_dim)
+    k = int(_lib.lib().slm_paged_kv_varlen_mha_decode_kernel(C.byref(a)))
+    if k < 0:
+        raise SlmError("slm_paged_kv_varlen_mha_decode_kernel: invalid attention arguments")
+    return "attn_tile_kernel" if k == 1 else "attn_token_kernel"
+
+
 # ---------------------------------------------------------------------------------------
 # KV append
 # ---------------------------------------------------------------------------------------
@@ -311,9 +333,12 @@ class PackedW4:
     (qlinear_awq_marlin_impl.cpp:99-125,232-235; qlinear_gptq_marlin_impl.cpp:41-71,181-184).
     """
 
-    def __init__(self, wq, sz, perm, K, N, group_size, dtype, paired=False):
+    def __init__(self, wq, sz, perm, K, N, group_size, dtype, paired=False, k_src=None):
         self.wq, self.sz, self.perm = wq, sz, perm
         self.K, self.N, self.group_size, self.dtype = K, N, group_size, dtype
+        # k_src: width of the activations the GEMM takes.  Equal to K except for a padded
+        # act-order shard (gptq_repack with uneven groups), whose packed K is larger
+        self.k_src = K if k_src is None else k_src
         # paired: a merged [gate | up] weight whose packed column tiles alternate gate / up
         # (SLM_W4_PAIRED) -- the form gptq_gemm(..., silu_mul=True) needs
         self.paired = paired
@@ -378,11 +403,73 @@ def gptq_repack(qweight: torch.Tensor,  # [K/8, N] int32
         trivial = torch.arange(K, device=g_idx.device, dtype=torch.int64) // gs
         if not torch.equal(g_idx.to(torch.int64), trivial):
             perm64 = torch.argsort(g_idx.to(torch.int64), stable=True)
-            # the kernel needs whole groups after sorting (every group has group_size rows)
             if not torch.equal(g_idx.to(torch.int64)[perm64], trivial):
-                raise SlmError("act-order g_idx with uneven groups is not supported")
+                # uneven groups after sorting: a row-parallel shard of an act-order checkpoint
+                # (sharded qweight / g_idx, FULL scales: qlinear_gptq_marlin_impl.cpp:236-243,270-276;
+                # the reference then runs Marlin with is_k_full = false, :319)
+                return _prepack_uneven_groups(qweight, qzeros, scales, g_idx.to(torch.int64), perm64,
+                                              K, N, gs, paired)
             perm = perm64.to(torch.int32).contiguous()
     return _prepack(_lib.SLM_W4_GPTQ, qweight, qzeros, scales, perm, K, N, gs, paired)
+
+
+_UNEVEN_BLOCK = 32  # smallest scale-group the kernels support: padding granule of an uneven shard
+
+
+def plan_uneven_groups(g_idx: torch.Tensor, perm: torch.Tensor, n_groups: int):
+    """Padded row order of an act-order shard whose groups hold uneven numbers of rows.
+
+    g_idx [K] int64: group of every checkpoint row of the shard (indices into the FULL scale
+    table); perm = argsort(g_idx, stable).  The sorted rows of every group are padded up to a
+    multiple of 32 rows and the total up to a multiple of 128, so that in the padded order every
+    32-row block belongs to exactly one group -- which the kernels handle as group_size = 32 with
+    one scale row per block.  Returns (perm_p [Kp] int32: padded position -> checkpoint row, -1 =
+    padding; block_group [Kp / 32] int64)."""
+    B = _UNEVEN_BLOCK
+    dev = g_idx.device
+    gs_sorted = g_idx[perm]
+    counts = torch.bincount(gs_sorted, minlength=n_groups)
+    padded = (counts + B - 1) // B * B
+    starts = torch.cumsum(padded, 0) - padded    # first padded position of every group
+    cstarts = torch.cumsum(counts, 0) - counts   # first sorted position of every group
+    pos = starts[gs_sorted] + (torch.arange(g_idx.numel(), device=dev) - cstarts[gs_sorted])
+    total = int(padded.sum().item())
+    kp = (total + 127) // 128 * 128
+    perm_p = torch.full((kp,), -1, dtype=torch.int32, device=dev)
+    perm_p[pos] = perm.to(torch.int32)
+    block_group = torch.repeat_interleave(torch.arange(n_groups, device=dev), padded // B)
+    if kp > total:  # tail blocks: all padding, any scale row will do
+        block_group = torch.cat([block_group, block_group.new_zeros((kp - total) // B)])
+    return perm_p.contiguous(), block_group
+
+
+def _prepack_uneven_groups(qweight, qzeros, scales, g_idx, perm64, K, N, gs, paired) -> PackedW4:
+    L = _lib.lib()
+    _require_gpu(qweight, qzeros, scales)
+    G = scales.size(0)
+    if int(g_idx.max().item()) >= G or int(g_idx.min().item()) < 0:
+        raise SlmError("g_idx refers to a scale group the scales tensor does not have")
+    if tuple(qzeros.shape) != (G, N // 8) or scales.size(1) != N or not scales.is_contiguous():
+        raise SlmError(f"scales/qzeros shapes do not match n_groups={G} N={N}")
+    perm_p, block_group = plan_uneven_groups(g_idx, perm64, G)
+    kp = perm_p.numel()
+    fmt = _lib.SLM_W4_GPTQ
+    if paired:
+        if N % 64:
+            raise SlmError(f"paired (gate | up) prepack needs N % 64 == 0, got N={N}")
+        fmt |= _lib.SLM_W4_PAIRED
+    nb_w = L.slm_w4_packed_weight_bytes(kp, N)
+    if nb_w == 0:
+        raise SlmError(f"unsupported int4 shape K={kp} N={N}")
+    wq = torch.empty(nb_w // 4, dtype=torch.int32, device=qweight.device)
+    check(L.slm_w4_prepack_weights(fmt, qweight.data_ptr(), perm_p.data_ptr(), kp, N, wq.data_ptr(),
+                                   _stream()), "slm_w4_prepack_weights")
+    # fused {scale, magic + zero} rows of the FULL table, then one row per 32-row block
+    sz_full = torch.empty(G * N, dtype=torch.int32, device=qweight.device)
+    check(L.slm_w4_prepack_sz(fmt, qzeros.data_ptr(), scales.data_ptr(), G * gs, N, gs,
+                              _dtype_code(scales), sz_full.data_ptr(), _stream()), "slm_w4_prepack_sz")
+    sz = sz_full.view(G, N)[block_group].contiguous().view(-1)
+    return PackedW4(wq, sz, perm_p, kp, N, _UNEVEN_BLOCK, scales.dtype, paired, k_src=K)
 
 
 def _gemm_args(a, packed: PackedW4, c, bias, silu_mul=False) -> W4GemmArgs:
@@ -392,7 +479,7 @@ def _gemm_args(a, packed: PackedW4, c, bias, silu_mul=False) -> W4GemmArgs:
     if silu_mul and not packed.paired:
         raise SlmError("silu_mul=True needs weights packed with paired=True (gate | up tiles interleaved)")
     n_out = packed.N // 2 if silu_mul else packed.N
-    if a.size(1) != packed.K or c.size(1) != n_out or a.size(0) != c.size(0):
+    if a.size(1) != packed.k_src or c.size(1) != n_out or a.size(0) != c.size(0):
         raise SlmError("GEMM shape mismatch")
     if a.dtype != packed.dtype or c.dtype != packed.dtype:
         raise SlmError("activation / output dtype must match the prepacked scales dtype")

@@ -123,3 +123,32 @@ def test_bench_profiler_children_are_bounded(tmp_path, monkeypatch):
     t0 = time.time()
     traffic, why = bench.measure_attention_traffic_live(2, 64, 8, 2, 16, timeout_s=1.0)
     assert traffic is None and "TimeoutExpired" in why and time.time() - t0 < 10
+
+
+def test_plan_uneven_groups_of_an_act_order_shard():
+    """kernels.plan_uneven_groups (host logic of the row-parallel act-order path): in the padded order
+    every 32-row block holds rows of ONE group, every checkpoint row appears exactly once, padding
+    rows are -1, the total is a multiple of 128 -- for random shards of random act-order layers."""
+    import torch
+    from scalellm_amd import kernels
+    rng = np.random.default_rng(5)
+    for K, gs, world in ((1024, 128, 2), (4096, 128, 8), (2048, 64, 4), (512, 32, 2), (28672 // 8, 128, 8)):
+        k_full = K * world if K == 28672 // 8 else K
+        g_full = (np.arange(k_full) // gs)[rng.permutation(k_full)]
+        ks = k_full // world
+        r = int(rng.integers(0, world))
+        g_idx = torch.from_numpy(g_full[r * ks:(r + 1) * ks].astype(np.int64))
+        perm = torch.argsort(g_idx, stable=True)
+        n_groups = k_full // gs
+        perm_p, block_group = kernels.plan_uneven_groups(g_idx, perm, n_groups)
+        kp = perm_p.numel()
+        assert kp % 128 == 0 and block_group.numel() == kp // 32
+        real = perm_p[perm_p >= 0]
+        assert sorted(real.tolist()) == list(range(ks))
+        rows_group = torch.where(perm_p >= 0, g_idx[perm_p.clamp(min=0).long()], torch.full_like(perm_p, -1).long())
+        blocks = rows_group.view(-1, 32)
+        for b in range(blocks.size(0)):
+            gset = set(blocks[b][blocks[b] >= 0].tolist())
+            assert len(gset) <= 1 and (not gset or gset == {int(block_group[b])})
+        # padding overhead is bounded by 31 rows per group present + the 128-row tail
+        assert kp <= ks + 31 * int((torch.bincount(g_idx, minlength=n_groups) > 0).sum()) + 127

@@ -84,27 +84,23 @@ def pack_awq_weights(q_w):
 @pytest.mark.parametrize("m", [16, 32, 64])
 @pytest.mark.parametrize("n", [64, 128, 256, 512])
 @pytest.mark.parametrize("k", [128, 256])
-@pytest.mark.parametrize("num_bits", [4, 8])
+@pytest.mark.parametrize("num_bits", [4])
 @pytest.mark.parametrize("group_size", [-1, 32, 64, 128])
 @pytest.mark.parametrize("act_order", [False, True])
 @pytest.mark.parametrize("is_k_full", [False, True])
 @pytest.mark.parametrize("use_fp32_reduce", [False, True])
 def test_marlin_gemm(kernels, m, n, k, num_bits, group_size, act_order, is_k_full, use_fp32_reduce):
+    # the reference's grid (marlin_gemm_test.py:47-56) has num_bits {4, 8}: the 8-bit half is ONE
+    # refusal test below, not 768 parametrisations of it.  is_k_full = False on these full-K layers
+    # is the same computation as True (every group is whole): the shim checks that from g_idx.
     if act_order and (group_size == -1 or group_size == k):
-        return  # act_order=True requires group_size < k
+        pytest.skip("act_order=True requires group_size < k (marlin_gemm_test.py:64)")
     gen = torch.Generator(device="cuda").manual_seed(m * 7 + n * 3 + k + group_size)
     a = torch.randn((m, k), dtype=torch.half, device="cuda", generator=gen)
     w = torch.randn((k, n), dtype=torch.half, device="cuda", generator=gen)
     w_ref, q_w, s, g_idx, _ = quantize_weights(w, num_bits=num_bits, group_size=group_size,
                                                act_order=act_order,
                                                generator=torch.Generator().manual_seed(k + n))
-    if num_bits == 8:
-        out = torch.empty(k // 16, n * 16 // 4, dtype=torch.int32, device="cuda")
-        with pytest.raises(RuntimeError, match="4-bit"):
-            kernels.marlin_gptq_repack(q_weight=torch.zeros(k // 4, n, dtype=torch.int32, device="cuda"),
-                                       perm=torch.empty(0, dtype=torch.int32, device="cuda"), out=out,
-                                       num_bits=8)
-        return
     # checkpoint-format weights -> this library's layout (rows sorted by group when act_order)
     gptq_q_w = pack_gptq_weights(q_w)
     if act_order:
@@ -124,6 +120,52 @@ def test_marlin_gemm(kernels, m, n, k, num_bits, group_size, act_order, is_k_ful
     output_ref = torch.matmul(a, w_ref)
     max_diff = torch.mean(torch.abs(output - output_ref)) / torch.mean(torch.abs(output_ref))
     assert max_diff < 0.001
+
+
+def test_marlin_8bit_weights_are_refused(kernels):
+    """The int8 Marlin path (qlinear_awq_marlin_impl.cpp:25-26 accepts bits 4 and 8) is outside this
+    hot path (all BASELINE configs are int4): the entry points refuse it loudly."""
+    k, n = 128, 64
+    out = torch.empty(k // 16, n * 16 // 4, dtype=torch.int32, device="cuda")
+    empty = torch.empty(0, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="4-bit"):
+        kernels.marlin_gptq_repack(q_weight=torch.zeros(k // 4, n, dtype=torch.int32, device="cuda"),
+                                   perm=empty, out=out, num_bits=8)
+    with pytest.raises(RuntimeError, match="4-bit"):
+        kernels.marlin_gemm(A=torch.zeros(16, k, dtype=torch.half, device="cuda"), B=out,
+                            C=torch.empty(16, n, dtype=torch.half, device="cuda"),
+                            scales=torch.ones(1, n, dtype=torch.half, device="cuda"), zeros=empty, g_idx=empty,
+                            perm=empty, workspace=empty, num_bits=8, is_k_full=True, has_zp=False,
+                            use_fp32_reduce=True)
+
+
+def test_marlin_gemm_refuses_an_uneven_act_order_shard_and_sweeps_its_table_cache(kernels):
+    """is_k_full = False with a g_idx whose groups are NOT whole (a row-parallel act-order shard) cannot
+    be expressed on weights packed at checkpoint size: refused, with a pointer to the layer class.
+    And the fused {scale, zero} table cache behind gptq_gemm drops the tables of freed parameters."""
+    m, k, n, gs = 16, 256, 64, 64
+    gen = torch.Generator().manual_seed(1)
+    q_w = torch.randint(0, 16, (k, n), generator=gen, dtype=torch.int32).cuda()
+    packed = torch.empty(k // 16, n * 16 // 8, dtype=torch.int32, device="cuda")
+    g_idx_sorted = (torch.arange(k) // gs).to(torch.int32)
+    g_idx_sorted[gs - 1] = 1                                  # group 0 one row short, group 1 one too many
+    perm = torch.arange(k, dtype=torch.int32).cuda()
+    kernels.marlin_gptq_repack(q_weight=pack_gptq_weights(q_w), perm=perm, out=packed, num_bits=4)
+    a = torch.randn(m, k, dtype=torch.half, device="cuda")
+    c = torch.empty(m, n, dtype=torch.half, device="cuda")
+    empty = torch.empty(0, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="RowParallelQLinearHipImpl"):
+        kernels.marlin_gemm(A=a, B=packed, C=c, scales=torch.ones(k // gs, n, dtype=torch.half, device="cuda"),
+                            zeros=empty, g_idx=g_idx_sorted.cuda(), perm=perm, workspace=empty, num_bits=4,
+                            is_k_full=False, has_zp=False, use_fp32_reduce=True)
+    before = kernels.marlin_sz_cache_entries()
+    for i in range(4):  # four generations of "reloaded" parameters: only the live one keeps its table
+        scales = torch.full((k // gs, n), 1.0 + i, dtype=torch.half, device="cuda")
+        kernels.marlin_gemm(A=a, B=packed, C=c, scales=scales, zeros=empty, g_idx=empty, perm=empty,
+                            workspace=empty, num_bits=4, is_k_full=True, has_zp=False, use_fp32_reduce=True)
+        torch.cuda.synchronize()
+        del scales
+    assert kernels.marlin_sz_cache_entries() <= before + 2
 
 
 def _dequant_through_gemm(kernels, packed, k, n, perm):

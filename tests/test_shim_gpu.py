@@ -212,6 +212,32 @@ def test_cpp_parallel_qlinear_impls_world1_and_tp2_sharding(shim, fmt):
     assert rel((parts[0] + parts[1] + bias.to(DEV).float()).to(torch.bfloat16)) < 8e-3
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_cpp_row_parallel_act_order_gptq_shards(shim, world):
+    """desc_act GPTQ under row-parallel TP through the C++ layer (the case the round-2 shim refused):
+    every rank loads its rows + its slice of g_idx and the FULL scales / zeros
+    (qlinear_gptq_marlin_impl.cpp:236-243,270-276), packs them with padded groups, and the summed
+    partial outputs equal the world-1 layer and the oracle (gptq_dequant with g_idx).  The raw
+    marlin::gptq_gemm entry point keeps refusing is_k_full = false."""
+    K, N, gs, M = 1024, 256, 128, 24
+    case = helpers.make_quant_case(77, K, N, gs, "gptq", "bf16", act_order=True)
+    sd = _ckpt(case)
+    args = ("gptq", 4, gs, True, False, False)   # bits, group, desc_act, is_sym, zero_point
+    a = torch.randn(M, K, device=DEV, dtype=torch.bfloat16)
+    ref = oracle.gemm_f32(a.float().cpu().numpy(), _oracle_dense(case))
+    rel = lambda got: float(np.abs(got.float().cpu().numpy() - ref).mean() / np.abs(ref).mean())  # noqa: E731
+    one = shim.create_row_parallel_qlinear(K, N, False, True, *args, 0, 1, torch.bfloat16, 0)
+    one.load_state_dict(sd)
+    assert rel(one.forward(a)) < 8e-3
+    total = torch.zeros(M, N, device=DEV, dtype=torch.float32)
+    for r in range(world):   # no process group: every rank returns its partial sums
+        lin = shim.create_row_parallel_qlinear(K, N, False, False, *args, r, world, torch.bfloat16, 0)
+        lin.load_state_dict(sd)
+        lin.verify_loaded_weights()
+        total += lin.forward(a).float()
+    assert rel(total) < 8e-3 * (1 + 0.5 * np.sqrt(world))
+
+
 def test_cpp_parallel_qlinear_fused_load_and_argument_checks(shim):
     """The fused (qkv / gate_up) load path: one checkpoint tensor set per prefix, arriving in any
     order and possibly in different state-dict files, concatenated on dim 1; and the reference's

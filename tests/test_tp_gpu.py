@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, fused_ar=False):
+def _worker(rank, world, port, q, fused_ar=False, desc_act=False):
     try:
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                           MASTER_PORT=str(port), LOCAL_RANK="0", SLM_DIST_BACKEND="gloo")
@@ -40,8 +40,9 @@ def _worker(rank, world, port, q, fused_ar=False):
             from scalellm_amd.custom_allreduce import try_create_xgmi_allreduce
             ar = try_create_xgmi_allreduce(rank, world, bs, shape.hidden, torch.bfloat16, dev)
             assert ar is not None, "fused all-reduce failed its self-test"
+        quant = dict(quant_method="gptq", desc_act=True) if desc_act else {}
         tp = LlamaDecodeStep(shape, bs, n_blocks, B, pa, dtype=torch.bfloat16, device=dev, seed=5,
-                             kv_fill="consistent", custom_allreduce=ar)
+                             kv_fill="consistent", custom_allreduce=ar, **quant)
         logits_tp = tp.forward(tokens, positions, params, return_logits=True).float().cpu()
         res = {"rank": rank, "shape": tuple(logits_tp.shape)}
         if fused_ar:
@@ -58,7 +59,7 @@ def _worker(rank, world, port, q, fused_ar=False):
             res["ar_error"] = ar.error()
         if rank == 0:
             ref = LlamaDecodeStep(shape, bs, n_blocks, B, ParallelArgs(), dtype=torch.bfloat16, device=dev,
-                                  seed=5, kv_fill="consistent")
+                                  seed=5, kv_fill="consistent", **quant)
             logits_ref = ref.forward(tokens, positions, params, return_logits=True).float().cpu()
             err = (logits_tp - logits_ref).abs().max().item()
             scale = logits_ref.abs().max().item()
@@ -94,3 +95,25 @@ def test_tp2_matches_tp1_on_one_gpu(fused_ar):
         assert all(r["ar_error"] == 0 for r in res), res
         assert all(r["fused_vs_plain"] == 0.0 for r in res), res
         assert all(r["greedy_ok"] for r in res), res
+
+
+@pytest.mark.timeout(300)
+def test_tp2_act_order_gptq_matches_tp1_on_one_gpu():
+    """GPTQ desc_act = true under TP = 2 (BASELINE configs[3] asks for one act-order
+    case): column-parallel layers keep the whole g_idx, row-parallel layers (o_proj, down_proj) shard
+    rows + g_idx and keep the FULL scales (qlinear_gptq_marlin_impl.cpp:236-243) -- the padded-group
+    packing of kernels.gptq_repack.  Logits must agree with the TP = 1 model built from the same
+    synthetic checkpoint (whose act-order layers take the even-group path)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, False, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+    assert all("fail" not in r for r in res), res
+    r0 = next(r for r in res if r["rank"] == 0)
+    assert r0["err"] <= 0.05 * r0["scale"] + 1e-3, r0
+    assert r0["agree"] >= 0.8, r0

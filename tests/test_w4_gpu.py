@@ -289,6 +289,40 @@ def test_k_sliced_small_m_kernel_grid(bits):
 
 
 @pytest.mark.parametrize("bits", ["bf16", "f16"])
+@pytest.mark.parametrize("world,M,K,N,gs", [(2, 24, 1024, 256, 128), (4, 5, 2048, 160, 64),
+                                            (8, 32, 4096, 256, 128), (2, 200, 1024, 384, 32)])
+def test_act_order_row_parallel_shards_match_the_full_layer(bits, world, M, K, N, gs):
+    """GPTQ act-order (desc_act) under row-parallel TP: rank r holds checkpoint rows
+    [r K/world, (r+1) K/world) with THEIR g_idx and the FULL scale / zero tables
+    (qlinear_gptq_marlin_impl.cpp:236-243,270-276); the rows of a shard hit every group an uneven
+    number of times (Marlin: is_k_full = false, :319).  Each rank's GEMM on its slice of the
+    activations gives a partial sum; their fp32 sum must match the oracle's full-layer GEMM
+    (gptq_dequant with g_idx) as well as the single-rank act-order path does."""
+    from scalellm_amd import kernels
+    case = helpers.make_quant_case(world * 100 + M, K, N, gs, "gptq", bits, act_order=True)
+    qweight, qzeros, scales, g_idx = _to_dev(case, bits)
+    dt = _tdtype(bits)
+    g = torch.Generator(device=DEV).manual_seed(world + K)
+    a = torch.randn(M, K, device=DEV, dtype=dt, generator=g)
+    total = torch.zeros(M, N, device=DEV, dtype=torch.float32)
+    ks = K // world
+    for r in range(world):
+        packed = kernels.gptq_repack(qweight[r * ks // 8:(r + 1) * ks // 8].contiguous(), qzeros, scales, gs,
+                                     g_idx[r * ks:(r + 1) * ks].contiguous())
+        assert packed.k_src == ks and packed.K >= ks and packed.K % 128 == 0 and packed.group_size == 32
+        c = torch.full((M, N), float("nan"), device=DEV, dtype=dt)
+        kernels.gptq_gemm(a[:, r * ks:(r + 1) * ks], packed, c)
+        total += c.float()
+    torch.cuda.synchronize()
+    ref = oracle.gemm_f32(a.float().cpu().numpy(), _oracle_w(case))
+    out = total.cpu().numpy()
+    assert not np.isnan(out).any()
+    # `world` partial sums were each rounded to T before the fp32 sum: allow that on top of the GEMM bound
+    err = _rel_err(out, ref)
+    assert err < GEMM_TOL[bits] * (1 + 0.5 * np.sqrt(world)), (world, M, K, N, gs, err)
+
+
+@pytest.mark.parametrize("bits", ["bf16", "f16"])
 def test_lean_small_m_kernel_still_covered(bits, tune):
     """w4_small.hip stays in the library for shapes the K-sliced kernel steps aside from (forced
     split-K counts it cannot realise, SLM_W4_KS=0): keep its grid alive."""
