@@ -84,18 +84,29 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
     }
     b = lo_b;
   }
+  // Balanced pure-decode partition (p.bal; plan_attn): this workgroup is number w of its head
+  // group and owns the tokens [g, g1) of the concatenated histories; it walks the sequences that
+  // range touches ("pieces"), each piece a complete pass of the body below with its own partial.
+  int bal_g = 0, bal_g1 = 0, bal_Q = 1;  // (all < 2^31: kv_cu is int32)
+  if (p.bal) {
+    const int W = p.kv_cu[p.batch];
+    bal_Q = attn_bal_q(p, W);
+    const int64_t g64 = (int64_t)(tok * p.n_splits + split) * bal_Q;
+    if (g64 >= (int64_t)W) return;
+    bal_g = (int)g64;
+    bal_g1 = W - bal_g > bal_Q ? bal_g + bal_Q : W;
+    int lo_b = 0, hi_b = p.batch;  // sequence holding token g: kv_cu[b] <= g < kv_cu[b + 1]
+    while (lo_b < hi_b) {
+      const int mid = (lo_b + hi_b) >> 1;
+      if (p.kv_cu[mid + 1] <= bal_g) lo_b = mid + 1; else hi_b = mid;
+    }
+    b = lo_b;
+  }
   if (b >= p.batch) return;  // padding token past q_cu[batch]
-  {
+  if (!p.bal) {
     const int rows = (p.q_cu[b + 1] - p.q_cu[b]) * p.group;
     if (rows < p.rows_lo || rows >= p.rows_hi) return;  // another launch owns this sequence
   }
-
-  const int q_start = p.q_cu[b];
-  const int q_len = p.q_cu[b + 1] - q_start;
-  const int kv_len = p.kv_cu[b + 1] - p.kv_cu[b];
-  const int diag = kv_len - q_len + (tok - q_start);  // last visible kv index (causal)
-  const int hi = min(diag + 1, kv_len);
-  const int lo = (p.window >= 0) ? max(0, diag - p.window) : 0;
 
   // lane / wave decomposition
   constexpr int UPW = 64 / LPR;
@@ -112,15 +123,42 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
   const int RPI = RP * RPW;  // rows per workgroup iteration
 
   const int kvh = (((hgb << p.hgw_shift) + hgw) << p.hpw_shift) + hsub;
-  const int qh0 = kvh * p.group + chunk * GC;
+  const int qh0_lane = kvh * p.group + chunk * GC;
   const bool act = (sub * 8) < p.head_dim;  // head_dim < 8*LPR leaves idle lanes (D = 40, 96)
+  const int sub_ld = act ? sub : 0;  // idle lanes (q = 0) re-read dims 0..7: finite, never stored
+  const char* kbase = reinterpret_cast<const char*>(p.kc) + 2 * ((int64_t)kvh * p.k_hs + sub_ld * 8);
+  const char* vbase = reinterpret_cast<const char*>(p.vc) + 2 * ((int64_t)kvh * p.v_hs + sub_ld * 8);
+  // slot stride in bytes (< 2^32: plan_attn checks); slot >= 0 -> one v_mad_u64_u32 per address
+  const uint32_t k_sb = (uint32_t)(2 * p.k_ss), v_sb = (uint32_t)(2 * p.v_ss);
+  float slope2[GC];
+#pragma unroll
+  for (int h = 0; h < GC; ++h) slope2[h] = p.alibi ? p.alibi[qh0_lane + h] * LOG2E : 0.f;
 
-  // split range, aligned to RPI rows
-  const int len = max(hi - lo, 0);
-  int per = (len + p.n_splits - 1) / p.n_splits;
-  per = ((per + RPI - 1) / RPI) * RPI;
-  const int s_lo = lo + split * per;
-  const int s_hi = min(hi, s_lo + per);
+  for (;;) {  // one pass per piece (classic partition: exactly one)
+  int tok_p = tok, s_lo, s_hi, part_idx = split;
+  bool single = p.n_splits == 1;  // the pass covers its sequence alone: it writes the final output
+  if (p.bal) {
+    const int kv0 = p.kv_cu[b], kv1 = p.kv_cu[b + 1];
+    tok_p = b;  // pure decode: token index == sequence index
+    s_lo = bal_g - kv0;
+    s_hi = min(kv1, bal_g1) - kv0;
+    const int w_first = kv0 / bal_Q;
+    part_idx = bal_g / bal_Q - w_first;
+    single = (kv1 - 1) / bal_Q == w_first;
+  } else {
+    const int q_start = p.q_cu[b];
+    const int q_len = p.q_cu[b + 1] - q_start;
+    const int kv_len = p.kv_cu[b + 1] - p.kv_cu[b];
+    const int diag = kv_len - q_len + (tok - q_start);  // last visible kv index (causal)
+    const int hi = min(diag + 1, kv_len);
+    const int lo = (p.window >= 0) ? max(0, diag - p.window) : 0;
+    // split range, aligned to RPI rows
+    const int len = max(hi - lo, 0);
+    int per = (len + p.n_splits - 1) / p.n_splits;
+    per = ((per + RPI - 1) / RPI) * RPI;
+    s_lo = lo + split * per;
+    s_hi = min(hi, s_lo + per);
+  }
 
   // q fragment: GC heads x 8 dims (packed pairs)
   uint32_t qv[GC][4];
@@ -131,14 +169,11 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
       const T* qp = reinterpret_cast<const T*>(p.q);
       (void)qp;
       const char* ptr = reinterpret_cast<const char*>(p.q) +
-                        2 * ((int64_t)tok * p.q_ts + (int64_t)(qh0 + h) * p.q_hs + sub * 8);
+                        2 * ((int64_t)tok_p * p.q_ts + (int64_t)(qh0_lane + h) * p.q_hs + sub * 8);
       t = *reinterpret_cast<const u32x4*>(ptr);
     }
     qv[h][0] = t.x; qv[h][1] = t.y; qv[h][2] = t.z; qv[h][3] = t.w;
   }
-  float slope2[GC];
-#pragma unroll
-  for (int h = 0; h < GC; ++h) slope2[h] = p.alibi ? p.alibi[qh0 + h] * LOG2E : 0.f;
 
   float m[GC], l[GC], o[GC][8];
 #pragma unroll
@@ -149,11 +184,6 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
     for (int j = 0; j < 8; ++j) o[h][j] = 0.f;
   }
 
-  const int sub_ld = act ? sub : 0;  // idle lanes (q = 0) re-read dims 0..7: finite, never stored
-  const char* kbase = reinterpret_cast<const char*>(p.kc) + 2 * ((int64_t)kvh * p.k_hs + sub_ld * 8);
-  const char* vbase = reinterpret_cast<const char*>(p.vc) + 2 * ((int64_t)kvh * p.v_hs + sub_ld * 8);
-  // slot stride in bytes (< 2^32: plan_attn checks); slot >= 0 -> one v_mad_u64_u32 per address
-  const uint32_t k_sb = (uint32_t)(2 * p.k_ss), v_sb = (uint32_t)(2 * p.v_ss);
   const int bcu0 = p.bcu[b];
 
   u32x4 kr[U], vr[U];
@@ -353,34 +383,47 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
     }
   }
 
-  if (rp != 0 || rsub != 0 || !act) return;
-
-  if (p.n_splits == 1) {
+  if (rp == 0 && rsub == 0 && act) {
+    // (opaque copy: keeps hipcc from hoisting the GC output addresses out of the piece loop, where
+    // they would sit in -- or spill from -- registers across the whole stream)
+    int qh0 = qh0_lane;
+    asm volatile("" : "+v"(qh0));
+    if (single) {
 #pragma unroll
-    for (int h = 0; h < GC; ++h) {
-      const float inv = l[h] > 0.f ? 1.0f / l[h] : 0.f;
-      u32x4 r;
-      r.x = pack2<T>(o[h][0] * inv, o[h][1] * inv);
-      r.y = pack2<T>(o[h][2] * inv, o[h][3] * inv);
-      r.z = pack2<T>(o[h][4] * inv, o[h][5] * inv);
-      r.w = pack2<T>(o[h][6] * inv, o[h][7] * inv);
-      char* ptr = reinterpret_cast<char*>(p.out) +
-                  2 * ((int64_t)tok * p.o_ts + (int64_t)(qh0 + h) * p.o_hs + sub * 8);
-      *reinterpret_cast<u32x4*>(ptr) = r;
-    }
-  } else {
+      for (int h = 0; h < GC; ++h) {
+        const float inv = l[h] > 0.f ? 1.0f / l[h] : 0.f;
+        u32x4 r;
+        r.x = pack2<T>(o[h][0] * inv, o[h][1] * inv);
+        r.y = pack2<T>(o[h][2] * inv, o[h][3] * inv);
+        r.z = pack2<T>(o[h][4] * inv, o[h][5] * inv);
+        r.w = pack2<T>(o[h][6] * inv, o[h][7] * inv);
+        char* ptr = reinterpret_cast<char*>(p.out) +
+                    2 * ((int64_t)tok_p * p.o_ts + (int64_t)(qh0 + h) * p.o_hs + sub * 8);
+        *reinterpret_cast<u32x4*>(ptr) = r;
+      }
+    } else {
 #pragma unroll
-    for (int h = 0; h < GC; ++h) {
-      const int64_t pi = ((int64_t)tok * p.n_heads + (qh0 + h)) * p.n_splits + split;
-      float* op = p.o_part + pi * p.head_dim + sub * 8;
-      *reinterpret_cast<f32x4*>(op) = f32x4{o[h][0], o[h][1], o[h][2], o[h][3]};
-      *reinterpret_cast<f32x4*>(op + 4) = f32x4{o[h][4], o[h][5], o[h][6], o[h][7]};
-      if (sub == 0) {
-        p.ml_part[pi * 2 + 0] = m[h];
-        p.ml_part[pi * 2 + 1] = l[h];
+      for (int h = 0; h < GC; ++h) {
+        const int64_t pi = ((int64_t)tok_p * p.n_heads + (qh0 + h)) * p.part_slots + part_idx;
+        float* op = p.o_part + pi * p.head_dim + sub * 8;
+        *reinterpret_cast<f32x4*>(op) = f32x4{o[h][0], o[h][1], o[h][2], o[h][3]};
+        *reinterpret_cast<f32x4*>(op + 4) = f32x4{o[h][4], o[h][5], o[h][6], o[h][7]};
+        if (sub == 0) {
+          p.ml_part[pi * 2 + 0] = m[h];
+          p.ml_part[pi * 2 + 1] = l[h];
+        }
       }
     }
   }
+  if (!p.bal) break;
+  // next piece: the following non-empty sequence, if this workgroup's range reaches into it
+  do {
+    ++b;
+  } while (b < p.batch && p.kv_cu[b + 1] == p.kv_cu[b]);
+  if (b >= p.batch) break;
+  bal_g = p.kv_cu[b];
+  if (bal_g >= bal_g1) break;
+  }  // piece loop
 }
 
 // out[tok, head, :] = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s   (one wave per (tok, head)).
@@ -415,11 +458,28 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const AttnKParams p, 
     const int rows = (p.q_cu[lo_b + 1] - p.q_cu[lo_b]) * p.group;
     if (rows < p.rows_lo || rows >= p.rows_hi) return;
   }
-  const float* ml = p.ml_part + item * p.n_splits * 2;
+  int n_used = p.n_splits;
+  if (p.bal) {
+    // balanced pure-decode partition: the pieces of sequence tok come from the consecutive
+    // workgroups floor(kv_cu[tok] / Q) .. floor((kv_cu[tok + 1] - 1) / Q) (attn_common.h)
+    if (!valid || tok >= p.batch) return;
+    const int kv0 = p.kv_cu[tok], kv1 = p.kv_cu[tok + 1];
+    if (kv1 <= kv0) {  // no history: nobody streamed this sequence -- the output row is zero
+      const int d0z = lane * 4;
+      if (d0z < p.head_dim)
+        *reinterpret_cast<u32x2*>(reinterpret_cast<char*>(p.out) +
+                                  2 * ((int64_t)tok * p.o_ts + (int64_t)head * p.o_hs + d0z)) = u32x2{0u, 0u};
+      return;
+    }
+    const int Q = attn_bal_q(p, p.kv_cu[p.batch]);
+    n_used = (kv1 - 1) / Q - kv0 / Q + 1;
+    if (n_used == 1) return;  // the one piece wrote the final output itself
+  }
+  const float* ml = p.ml_part + item * p.part_slots * 2;
   // every load below is UNCONDITIONAL (index clamped, result masked afterwards): a load inside a
   // branch makes hipcc wait for it at the join, which turns independent loads into a chain of HBM
   // round trips (tools/probes/experiments/attn_in_kernel_combine.md)
-  const int s_last = p.n_splits - 1;
+  const int s_last = n_used - 1;
   float mreg[4], lreg[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -432,7 +492,7 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const AttnKParams p, 
   const int n_phase = 64 >> lps_shift;
   const int d0 = (lane & (LPS - 1)) * 4;
   const bool actd = d0 < p.head_dim;  // idle dim lanes (head_dim < 4 LPS) re-read dims 0..3
-  const float* op = p.o_part + item * p.n_splits * p.head_dim + (actd ? d0 : 0);
+  const float* op = p.o_part + item * p.part_slots * p.head_dim + (actd ? d0 : 0);
   // first batch of O loads: issued BEFORE the weights are known (they do not depend on them)
   constexpr int NFIRST = 8;
   f32x4 first[NFIRST];
@@ -495,7 +555,11 @@ struct AttnPlan {
   int lpr, gc, hpw_shift, hgw_shift, nhgb, n_chunks, nw, n_splits, u;
   bool nt;
   size_t lds_bytes;
+  // balanced pure-decode partition (AttnKParams::bal): partial slots per (token, head) and the
+  // piece-size floor that keeps a sequence's pieces within them
+  int bal, part_slots, bal_qmin;
 };
+constexpr int ATTN_BAL_ALIGN = 64;
 
 // q_len = 1 sequences on the MFMA tile kernel?  With a wide GQA group the token kernel's VALU work
 // per KV byte (one dot-product / P.V chain per query head) is what bounds it -- G = 8: 4.4-5.3 TB/s
@@ -610,6 +674,34 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
   }
   if (n_splits > COMBINE_MAX_SPLITS) n_splits = COMBINE_MAX_SPLITS;
   pl->n_splits = n_splits;
+  // Pure decode on the token kernel: the SAME number of workgroups, but each takes an equal share
+  // of the batch's concatenated KV tokens instead of 1 / n_splits of its own sequence.  With one
+  // round of resident workgroups (bs >= 128) the classic partition finishes with the LONGEST
+  // sequence -- kv_len ~ U[2048, 4096] ran at 5.75 TB/s against 6.73 uniform
+  // (profiles/r03_attn_serving.jsonl); the lengths live on the device, so the partition is derived
+  // there (kv_cu_lens is its own prefix sum).  A sequence is cut into at most
+  // ceil(len / Q) + 1 pieces; Q >= max_kv_len / (slots - 1) bounds that by the partial slots.
+  // Uniform batches come out as one piece per sequence: final output written directly, the
+  // combine launch exits.  Not with a caller-forced split count (tests pin the classic form),
+  // not with a sliding window (the visible range is no longer a prefix sum).
+  pl->bal = 0;
+  pl->part_slots = n_splits;
+  pl->bal_qmin = 1;
+  // Measured (profiles/r03_attn_serving.jsonl, classic -> balanced): bs = 256 ragged 5.80 -> 6.43 TB/s,
+  // uniform 6.91 -> 6.85 (the combine launch that only exits); bs = 32 ragged 5.07 -> 5.37, uniform
+  // 5.73 -> 5.65; bs = 8 loses both ways (few sequences: the binary search and the piece
+  // bookkeeping are not amortised) -- hence the batch floor.  SLM_ATTN_BAL: 0 = never, 2 = always.
+  const int bal_mode = tune_get(TUNE_ATTN_BAL, 1);
+  if (bal_mode != 0 && (a->n_tokens >= 16 || bal_mode == 2) && a->max_q_len <= 1 && a->n_tokens == a->batch_size &&
+      a->sliding_window < 0 && forced_splits <= 0 && !decode_on_tile(a) && a->n_tokens > 0) {
+    int slots = n_splits + 1 > 9 ? n_splits + 1 : 9;
+    if (slots > COMBINE_MAX_SPLITS) slots = COMBINE_MAX_SPLITS;
+    pl->bal = 1;
+    pl->part_slots = slots;
+    const int64_t qmin = (a->max_kv_len + slots - 2) / (slots - 1);
+    pl->bal_qmin = (int)(qmin > 1 ? qmin : 1);
+    if (pl->n_splits >= slots) pl->n_splits = slots - 1;  // P = n_tokens * n_splits workgroups per head group
+  }
   pl->u = tune_get(TUNE_ATTN_U, 4);
   if (pl->u != 2 && pl->u != 4) pl->u = 4;
   pl->nt = tune_get(TUNE_ATTN_NT, a->max_q_len <= 1 ? 1 : 0) != 0;
@@ -678,8 +770,8 @@ SLM_API int32_t slm_paged_kv_varlen_mha_decode_kernel(const slm_attn_args* a) {
 SLM_API size_t slm_paged_kv_varlen_mha_workspace_bytes(const slm_attn_args* a) {
   AttnPlan pl;
   if (plan_attn(a, &pl) != SLM_OK) return 0;
-  if (pl.n_splits <= 1) return 0;
-  return (size_t)a->n_tokens * a->n_heads * pl.n_splits * (a->head_dim + 2) * sizeof(float);
+  if (pl.n_splits <= 1 && !pl.bal) return 0;
+  return (size_t)a->n_tokens * a->n_heads * pl.part_slots * (a->head_dim + 2) * sizeof(float);
 }
 
 SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
@@ -736,12 +828,13 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
   // A forced split count or an unsupported head_dim keeps everything on the token-major kernel.
   kp.rows_lo = 0;
   kp.rows_hi = 0x7fffffff;
-  if (pl.n_splits > 1) {
+  kp.bal = pl.bal; kp.part_slots = pl.part_slots; kp.bal_qmin = pl.bal_qmin; kp.bal_align = ATTN_BAL_ALIGN;
+  if (pl.n_splits > 1 || pl.bal) {
     const size_t need =
-        (size_t)a->n_tokens * a->n_heads * pl.n_splits * (a->head_dim + 2) * sizeof(float);
+        (size_t)a->n_tokens * a->n_heads * pl.part_slots * (a->head_dim + 2) * sizeof(float);
     if (!a->workspace || a->workspace_bytes < need) return SLM_ERR_WORKSPACE;
     kp.o_part = reinterpret_cast<float*>(a->workspace);
-    kp.ml_part = kp.o_part + (size_t)a->n_tokens * a->n_heads * pl.n_splits * a->head_dim;
+    kp.ml_part = kp.o_part + (size_t)a->n_tokens * a->n_heads * pl.part_slots * a->head_dim;
   }
   bool tile_used = false;
   const bool dec_tile = decode_on_tile(a);
@@ -779,7 +872,7 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
     rc = hip_check_launch();
     if (rc != SLM_OK) return rc;
   }
-  if (pl.n_splits > 1) {
+  if (pl.n_splits > 1 || pl.bal) {
     const int64_t items = (int64_t)a->n_tokens * a->n_heads;
     const dim3 g((unsigned)((items + 3) / 4)), blk(256);
     int lps_shift = 3;  // lanes per split: power of two >= head_dim / 4

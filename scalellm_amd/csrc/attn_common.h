@@ -19,8 +19,8 @@ struct AttnKParams {
   const int* bt;
   const int* bcu;
   const float* alibi;
-  float* o_part;   // [n_tokens, n_heads, n_splits, head_dim]
-  float* ml_part;  // [n_tokens, n_heads, n_splits, 2]
+  float* o_part;   // [n_tokens, n_heads, part_slots, head_dim]
+  float* ml_part;  // [n_tokens, n_heads, part_slots, 2]
   int batch, n_tokens, n_heads, n_kv_heads, head_dim;
   int block_shift, block_mask;
   int group;      // q heads per kv head
@@ -36,7 +36,24 @@ struct AttnKParams {
   // mixed batches: a launch only processes sequences with rows_lo <= q_len * group < rows_hi
   // (device-side lengths); the other classes belong to the other launches of the same call
   int rows_lo, rows_hi;
+  // balanced pure-decode partition (attn.hip, plan_attn): workgroup w of a head group streams the
+  // KV tokens [w Q, (w + 1) Q) of the CONCATENATED histories of the batch, Q = max(ceil(W / P),
+  // bal_qmin) rounded up to bal_align, W = kv_cu[batch], P = n_tokens * n_splits -- equal work per
+  // workgroup whatever the spread of the sequence lengths.  A sequence is then covered by
+  // pieces of consecutive workgroups: piece j of sequence b lives in partial slot j.
+  int bal;         // 0 = classic (every sequence split into n_splits equal parts)
+  int bal_qmin;    // bounds the pieces of one sequence by part_slots
+  int bal_align;
+  int part_slots;  // partial slots per (token, head): n_splits (classic) or the piece bound (balanced)
 };
+
+// the piece size of the balanced partition: ONE formula for the stream kernel and the combine kernel
+__device__ __forceinline__ int attn_bal_q(const AttnKParams& p, int W) {
+  const int P = p.n_tokens * p.n_splits;
+  int q = (W + P - 1) / P;
+  q = q > p.bal_qmin ? q : p.bal_qmin;
+  return (q + p.bal_align - 1) / p.bal_align * p.bal_align;
+}
 
 // tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e)); saturates correctly at +-inf, abs error ~1e-7
 // (the reference kernel uses tanh.approx: common/fast_math.h:30-60).

@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
     // whose loads are unconditional (an unwritten partial would be combined as garbage)
     if (!jvalid) return;
     if (p.n_splits > 1) {
-      const int64_t pi = ((int64_t)(q_start + tq) * p.n_heads + head) * p.n_splits + split;
+      const int64_t pi = ((int64_t)(q_start + tq) * p.n_heads + head) * p.part_slots + split;
       float* opp = p.o_part + pi * HD;
       for (int d = 4 * hh; d < HD; d += 8) *reinterpret_cast<f32x4*>(opp + d) = f32x4{0.f, 0.f, 0.f, 0.f};
       if (hh == 0) {
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
   if (p.n_splits > 1) {
     // split-KV partials in the token-major kernel's format (combined by attn_combine_kernel):
     // un-normalised O (fp32), running max (log2 domain) and sum of this KV share
-    const int64_t pi = ((int64_t)(q_start + tq) * p.n_heads + head) * p.n_splits + split;
+    const int64_t pi = ((int64_t)(q_start + tq) * p.n_heads + head) * p.part_slots + split;
     float* opp = p.o_part + pi * HD;
 #pragma unroll
     for (int d = 0; d < DT; ++d)

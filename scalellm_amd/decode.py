@@ -371,6 +371,38 @@ class LlamaDecodeStep:
         return (best * vs + local).to(torch.int32)
 
 
+def make_batch_inputs(q_lens, kv_lens, block_size: int, device, seed: int = 0, vocab: int = 128256):
+    """Synthetic MIXED batch in the engine's input format (engine/batch.cpp:77-270): sequence i
+    brings q_lens[i] new tokens (1 = decode, k + 1 = speculative verify, a chunk = chunked prefill)
+    on top of kv_lens[i] - q_lens[i] tokens of history (kv_lens INCLUDE the new tokens, as
+    kv_cu_seq_lens does); blocks are a seeded random permutation (unique first-slot ids, block 0
+    unused).  What BASELINE configs[4] batches look like, and the ragged decode batch of SURVEY
+    8(d) config 2 (q_lens all 1, kv_lens ~ U[2048, 4096])."""
+    import numpy as np
+    q_lens = [int(x) for x in q_lens]
+    kv_lens = [int(x) for x in kv_lens]
+    assert len(q_lens) == len(kv_lens) and all(0 < q <= k for q, k in zip(q_lens, kv_lens))
+    g = torch.Generator(device=device).manual_seed(seed)
+    nblk = [(k + block_size - 1) // block_size for k in kv_lens]
+    n_blocks = sum(nblk) + 2
+    perm = torch.randperm(n_blocks - 1, device=device, generator=g)[:sum(nblk)] + 1
+    table = (perm * block_size).to(torch.int32)
+    i32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int32)).to(device)  # noqa: E731
+    cu_blk = i32(np.concatenate([[0], np.cumsum(nblk)]))
+    q_cu = i32(np.concatenate([[0], np.cumsum(q_lens)]))
+    kv_cu = i32(np.concatenate([[0], np.cumsum(kv_lens)]))
+    pos = np.concatenate([np.arange(k - q, k) for q, k in zip(q_lens, kv_lens)])
+    blk0 = np.repeat(np.cumsum([0] + nblk[:-1]), q_lens)
+    positions = i32(pos)
+    blk_of = torch.from_numpy(blk0 + pos // block_size).to(device)
+    slots = (table[blk_of.long()].long() + torch.from_numpy(pos % block_size).to(device)).to(torch.int32)
+    tokens = torch.randint(0, vocab, (sum(q_lens),), device=device, generator=g).to(torch.int32)
+    params = InputParameters(q_cu_seq_lens=q_cu, kv_cu_seq_lens=kv_cu, new_cache_slots=slots,
+                             block_tables=table, cu_block_lens=cu_blk, q_max_seq_len=max(q_lens),
+                             kv_max_seq_len=max(kv_lens))
+    return tokens, positions, params, n_blocks
+
+
 def make_decode_inputs(batch: int, kv_len: int, block_size: int, device, seed: int = 0,
                        q_len: int = 1, vocab: int = 128256, spare_blocks: int = 0):
     """Synthetic decode batch in the engine's input format (engine/batch.cpp:77-270): every

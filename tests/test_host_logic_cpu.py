@@ -29,6 +29,35 @@ def test_decode_inputs_follow_engine_format():
         assert tokens.numel() == bs * q_len
 
 
+def test_mixed_batch_inputs_follow_engine_format():
+    """make_batch_inputs: per-sequence q_len / kv_len (decode + speculative verify + prefill chunks in
+    one batch, ragged histories), slots of the NEW tokens = the oracle's block-table arithmetic
+    (batch.cpp:197-211) at positions kv_len - q_len .. kv_len - 1."""
+    from scalellm_amd.decode import make_batch_inputs
+    rng = np.random.default_rng(2)
+    for B in (8, 16, 64):
+        q_lens = [1, 5, 1, 40, 3, 1]
+        kv_lens = [int(x) for x in rng.integers(41, 300, size=6)]
+        tokens, positions, p, n_blocks = make_batch_inputs(q_lens, kv_lens, B, torch.device("cpu"), seed=B,
+                                                           vocab=500)
+        table = p.block_tables.numpy()
+        nblk = [(k + B - 1) // B for k in kv_lens]
+        assert table.shape == (sum(nblk),) and np.all(table % B == 0) and table.min() >= B
+        assert len(set(table.tolist())) == sum(nblk) and table.max() < n_blocks * B
+        assert np.array_equal(p.cu_block_lens.numpy(), np.concatenate([[0], np.cumsum(nblk)]))
+        assert np.array_equal(p.q_cu_seq_lens.numpy(), np.concatenate([[0], np.cumsum(q_lens)]))
+        assert np.array_equal(p.kv_cu_seq_lens.numpy(), np.concatenate([[0], np.cumsum(kv_lens)]))
+        assert p.q_max_seq_len == 40 and p.kv_max_seq_len == max(kv_lens)
+        all_slots = oracle.all_slots(table, p.cu_block_lens.numpy(), p.kv_cu_seq_lens.numpy(), B)
+        kv_cu = np.concatenate([[0], np.cumsum(kv_lens)])
+        want = np.concatenate([all_slots[kv_cu[i] + kv_lens[i] - q_lens[i]:kv_cu[i] + kv_lens[i]]
+                               for i in range(len(q_lens))])
+        assert np.array_equal(p.new_cache_slots.numpy(), want)
+        assert np.array_equal(positions.numpy(),
+                              np.concatenate([np.arange(k - q, k) for q, k in zip(q_lens, kv_lens)]))
+        assert tokens.numel() == sum(q_lens)
+
+
 def test_algorithmic_bytes_match_survey():
     import bench
     # SURVEY 8d / BASELINE.md: 8B decode bs=256, L=4096, B=16 -> 4.2994 GB per layer call
