@@ -1,10 +1,7 @@
 #!/bin/bash
 set -x
 mkdir -p gpurun_out
-R=$PWD
-timeout 600 python tools/bench_config5.py --steps 10 --warmup 3 > gpurun_out/r03_config5.json 2> gpurun_out/config5.err
-cat gpurun_out/r03_config5.json
-timeout 600 bash tools/prof_summarize.sh r03_config5_prof --kernel-trace --stats -- python $R/tools/bench_config5.py --steps 3 --warmup 1
-head -30 gpurun_out/r03_config5_prof/*kernel_stats.csv | cut -c1-200
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/r03_bench_mid.json 2>gpurun_out/bench_mid.err
-cut -c1-900 gpurun_out/r03_bench_mid.json
+timeout 900 python -m pytest tests/test_w4_gpu.py tests/test_w4_silu_gpu.py -m gpu -q -x 2>&1 | tail -5
+V="SLM_W4_RT=0;AUTO;SLM_W4_SPLITK=1;SLM_W4_SPLITK=1,SLM_W4_KS_DBG=3;SLM_W4_SPLITK=1,SLM_W4_KS_DBG=16"
+timeout 900 python tools/bench_small_gemm.py --m 256,128 --check --rounds 5 --variants "$V" 2>&1 | grep -v amdgpu.ids | cut -c1-250
+timeout 900 python tools/bench_small_gemm.py --m 128 --check --rounds 5 --shapes qkv70,o70,gate_up70,down70 --variants "SLM_W4_RT=0;AUTO" 2>&1 | grep -v amdgpu.ids | cut -c1-250
