@@ -343,22 +343,39 @@ def _probe_xgmi_main():
     bs, hidden = int(os.environ["SLM_PROBE_BS"]), int(os.environ["SLM_PROBE_HIDDEN"])
     ar = try_create_xgmi_allreduce(rank, world, bs, hidden, torch.bfloat16, dev)
     ok = ar is not None
-    if ok:  # the launch must also survive capture + replay (what the timed step does)
+    if ok:
+        # The launch must also survive capture + replay, and in the SEQUENCE the timed step runs:
+        # the row-parallel int4 GEMM writes this rank's partial sums into the message buffer with PLAIN
+        # stores, and the very next graph node is the fused reduce whose peers read that buffer over
+        # the fabric (the kernel boundary writes the producer's L2 back; the peers' loads
+        # are sc0 sc1 and miss every cache).  A fill_() here would test a different producer.
+        from scalellm_amd import kernels as K
+        from scalellm_amd.decode import _rand_int4_linear
+        gen = torch.Generator(device=dev).manual_seed(99)          # same weights and activations on every rank
+        ck = _rand_int4_linear(gen, 256, hidden, 128, "awq", torch.bfloat16, dev)
+        packed = K.awq_repack(ck["qweight"], ck["qzeros"], ck["scales"], 128)
+        x = torch.randn(bs, 256, device=dev, dtype=torch.bfloat16, generator=gen)
+        part = torch.empty(bs, hidden, device=dev, dtype=torch.bfloat16)
+        K.gptq_gemm(x, packed, part)                                 # (also sizes the workspace before capture)
         w = torch.ones(hidden, device=dev, dtype=torch.bfloat16)
         res = torch.zeros(bs, hidden, device=dev, dtype=torch.bfloat16)
         out = torch.empty_like(res)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             for i in (0, 1):
-                ar.buffer(i, bs).fill_(1.0)
+                K.gptq_gemm(x, packed, ar.buffer(i, bs))
                 ar.allreduce_residual_rmsnorm(i, bs, out, res, w, 1e-5)
         for _ in range(3):
             res.zero_()
             g.replay()
         torch.cuda.synchronize()
         own = ar.owned_rows(bs)
-        # after a replay: first reduction leaves residual = world, the second 2 * world, on own rows
-        ok = ar.error() == 0 and bool((res[own.start:own.stop] == 2.0 * world).all().item())
+        # every rank contributed the same partial p: residual = bf16(world p) after the first reduction,
+        # bf16(world p + that) after the second -- exact in fp32 for world <= 8, compared bit for bit
+        p32 = part.float() * world
+        r1 = p32.to(torch.bfloat16)
+        r2 = (p32 + r1.float()).to(torch.bfloat16)
+        ok = ar.error() == 0 and torch.equal(res[own.start:own.stop], r2[own.start:own.stop])
     votes = [None] * world
     torch.distributed.all_gather_object(votes, bool(ok))
     if all(votes):

@@ -54,16 +54,16 @@ struct QuantArgs {  // layers/quantization/quant_args.h:10-33
 };
 
 struct ParallelArgs {  // model_parallel/parallel_args.h
-  ParallelArgs(int32_t rank, int32_t world_size, ProcessGroupRCCL* process_group)
+  ParallelArgs(int32_t rank, int32_t world_size, ProcessGroup* process_group)
       : rank_(rank), world_size_(world_size), process_group_(process_group) {}
   SLM_ARG(int32_t, rank) = 0;
   SLM_ARG(int32_t, world_size) = 0;
 
  public:
-  ProcessGroupRCCL* process_group() const { return process_group_; }
+  ProcessGroup* process_group() const { return process_group_; }
 
  private:
-  ProcessGroupRCCL* process_group_ = nullptr;
+  ProcessGroup* process_group_ = nullptr;
 };
 #undef SLM_ARG
 

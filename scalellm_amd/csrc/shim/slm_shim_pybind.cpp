@@ -178,7 +178,8 @@ PYBIND11_MODULE(_slm_shim, m) {
     int n = n_devices > 0 ? n_devices : static_cast<int>(torch::cuda::device_count());
     std::vector<torch::Device> devs;
     for (int i = 0; i < n; ++i) devs.emplace_back(torch::kCUDA, i);
-    auto pgs = slm::ProcessGroupRCCL::create_process_groups(devs);
+    // through the ABSTRACT interface (process_group.h:46-49), as every caller in the reference does
+    std::vector<std::unique_ptr<slm::ProcessGroup>> pgs = slm::ProcessGroup::create_process_groups(devs);
     std::vector<int> ok(n, 0);
     std::vector<std::thread> threads;
     for (int r = 0; r < n; ++r)
@@ -200,7 +201,25 @@ PYBIND11_MODULE(_slm_shim, m) {
             const auto want = torch::full({4, 8}, static_cast<float>(q + 1), torch::kHalf);
             ag = ag && torch::equal(flat.narrow(0, 4 * q, 4).cpu(), want) && torch::equal(outs[q].cpu(), want);
           }
-          ok[r] = (rep == 0 ? 1 : ok[r]) && ar && ag && pgs[r]->rank() == r && pgs[r]->world_size() == n;
+          // all-to-all, equal splits (process_group_test.cpp:110-140): rank r sends row q = 100 r + q to
+          // rank q and must end up with rows 100 q + r
+          auto a2a_in = (torch::arange(n, torch::dtype(torch::kFloat).device(devs[r])) + 100.f * r)
+                            .view({n, 1}).expand({n, 3}).contiguous();
+          auto a2a_out = torch::zeros({n, 3}, a2a_in.options());
+          pgs[r]->alltoall(a2a_in, a2a_out);
+          auto want_a2a = (torch::arange(n, torch::kFloat) * 100.f + static_cast<float>(r)).view({n, 1}).expand({n, 3});
+          bool aa = torch::equal(a2a_out.cpu(), want_a2a.contiguous());
+          // uneven splits (process_group_test.cpp:142-171): rank r sends q + 1 rows to rank q and
+          // receives r + 1 rows from everybody
+          std::vector<int64_t> in_split, out_split;
+          for (int q = 0; q < n; ++q) { in_split.push_back(q + 1); out_split.push_back(r + 1); }
+          auto u_in = torch::full({n * (n + 1) / 2, 2}, static_cast<float>(r), torch::dtype(torch::kFloat).device(devs[r]));
+          auto u_out = torch::full({n * (r + 1), 2}, -1.f, u_in.options());
+          pgs[r]->alltoall(u_in, u_out, in_split, out_split);
+          auto want_u = torch::arange(n, torch::kFloat).repeat_interleave(r + 1).view({-1, 1}).expand({n * (r + 1), 2});
+          aa = aa && torch::equal(u_out.cpu(), want_u.contiguous());
+          ok[r] = (rep == 0 ? 1 : ok[r]) && ar && ag && aa && pgs[r]->rank() == r && pgs[r]->world_size() == n &&
+                  pgs[r]->device() == devs[r];
         }
       });
     for (auto& t : threads) t.join();

@@ -577,30 +577,90 @@ ProcessGroupRCCL::~ProcessGroupRCCL() {
 
 void ProcessGroupRCCL::allreduce(torch::Tensor& input) const {
   check_input(input);
-  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_);
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device());
   nccl_check(ncclAllReduce(input.const_data_ptr(), input.mutable_data_ptr(), input.numel(),
                            to_nccl(input), ncclSum, static_cast<ncclComm_t>(comm_),
-                           c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(device_.index()).stream()),
+                           c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(device().index()).stream()),
              "ncclAllReduce");
 }
 
 void ProcessGroupRCCL::allgather(const torch::Tensor& input, torch::Tensor& outputs) const {
   check_input(input);
   check_input(outputs);
-  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device_);
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device());
   nccl_check(ncclAllGather(input.const_data_ptr(), outputs.mutable_data_ptr(), input.numel(),
                            to_nccl(input), static_cast<ncclComm_t>(comm_),
-                           c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(device_.index()).stream()),
+                           c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(device().index()).stream()),
              "ncclAllGather");
 }
 
 void ProcessGroupRCCL::allgather(const torch::Tensor& input,
                                  std::vector<torch::Tensor>& outputs) const {
-  TORCH_CHECK(static_cast<int>(outputs.size()) == world_size_);
-  auto flat = torch::empty({world_size_ * input.numel()}, input.options());
+  TORCH_CHECK(static_cast<int>(outputs.size()) == world_size());
+  auto flat = torch::empty({world_size() * input.numel()}, input.options());
   allgather(input, flat);
-  for (int r = 0; r < world_size_; ++r)
+  for (int r = 0; r < world_size(); ++r)
     outputs[r].copy_(flat.narrow(0, r * input.numel(), input.numel()).view_as(outputs[r]));
+}
+
+void ProcessGroupRCCL::alltoall(const torch::Tensor& input, torch::Tensor& output) const {
+  alltoall(input, output, {}, {});
+}
+
+// process_group.cpp:240-292 (check_split_sizes / compute_lengths_and_offsets :65-96): splits are
+// counted in ROWS (dim 0); an empty list = equal splits, which must then divide dim 0
+void ProcessGroupRCCL::alltoall(const torch::Tensor& input, torch::Tensor& output,
+                                const std::vector<int64_t>& input_split_sizes,
+                                const std::vector<int64_t>& output_split_sizes) const {
+  check_input(input);
+  check_input(output);
+  TORCH_CHECK(input.scalar_type() == output.scalar_type(), "input and output should have the same dtype");
+  TORCH_CHECK(input.device() == device() && output.device() == device(),
+              "tensors should be on the same device as the process group");
+  const int n = world_size();
+  auto lengths = [&](const std::vector<int64_t>& splits, const torch::Tensor& t, std::vector<size_t>& len,
+                     std::vector<size_t>& off) {
+    const int64_t rows = t.dim() > 0 ? t.size(0) : 1;
+    const int64_t row_numel = rows > 0 ? t.numel() / rows : 0;
+    if (splits.empty()) {
+      TORCH_CHECK(rows % n == 0, "tensor's dim 0 does not divide equally across the group size");
+    } else {
+      TORCH_CHECK(static_cast<int>(splits.size()) == n, "number of tensor splits not equal to group size");
+      int64_t sum = 0;
+      for (const auto v : splits) sum += v;
+      TORCH_CHECK(sum == rows, "split sizes do not match the total dim 0 size");
+    }
+    size_t o = 0;
+    for (int r = 0; r < n; ++r) {
+      const size_t l = static_cast<size_t>((splits.empty() ? rows / n : splits[r]) * row_numel);
+      len[r] = l;
+      off[r] = o;
+      o += l;
+    }
+  };
+  std::vector<size_t> slen(n), soff(n), rlen(n), roff(n);
+  lengths(input_split_sizes, input, slen, soff);
+  lengths(output_split_sizes, output, rlen, roff);
+  const size_t es = input.element_size();
+  const char* sb = reinterpret_cast<const char*>(input.const_data_ptr());
+  char* rb = reinterpret_cast<char*>(output.mutable_data_ptr());
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(device());
+  const auto stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(device().index()).stream();
+  const auto comm = static_cast<ncclComm_t>(comm_);
+  const auto type = to_nccl(input);
+  nccl_check(ncclGroupStart(), "ncclGroupStart");
+  for (int r = 0; r < n; ++r) {
+    nccl_check(ncclSend(sb + soff[r] * es, slen[r], type, r, comm, stream), "ncclSend");
+    nccl_check(ncclRecv(rb + roff[r] * es, rlen[r], type, r, comm, stream), "ncclRecv");
+  }
+  nccl_check(ncclGroupEnd(), "ncclGroupEnd");
+}
+
+std::vector<std::unique_ptr<ProcessGroup>> ProcessGroup::create_process_groups(
+    const std::vector<torch::Device>& devices) {
+  std::vector<std::unique_ptr<ProcessGroup>> out;
+  for (auto& pg : ProcessGroupRCCL::create_process_groups(devices)) out.push_back(std::move(pg));
+  return out;
 }
 
 // --------------------------------------------------------------------------------------------

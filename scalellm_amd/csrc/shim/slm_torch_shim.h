@@ -140,25 +140,55 @@ class W4Linear {
   torch::ScalarType dtype_;
 };
 
-// llm::ProcessGroup's contract over RCCL: one communicator per local GPU created together
+// The reference's abstract process group, same five virtuals with the same meaning
+// (src/model_parallel/process_group.h:10-60): whatever drives llm::ProcessGroup* -- the parallel
+// layers, Worker::process_group_test -- drives this.
+class ProcessGroup {
+ public:
+  ProcessGroup(int rank, int world_size, const torch::Device& device)
+      : rank_(rank), world_size_(world_size), device_(device) {}
+  virtual ~ProcessGroup() = default;
+  int rank() const { return rank_; }
+  int world_size() const { return world_size_; }
+  const torch::Device& device() const { return device_; }
+  // in-place SUM over all ranks
+  virtual void allreduce(torch::Tensor& input) const = 0;
+  virtual void allgather(const torch::Tensor& input, std::vector<torch::Tensor>& outputs) const = 0;
+  virtual void allgather(const torch::Tensor& input, torch::Tensor& outputs) const = 0;
+  // equal splits: rank r receives slice r of every rank's input
+  virtual void alltoall(const torch::Tensor& input, torch::Tensor& output) const = 0;
+  // splits along dim 0 (rows); an empty list means equal splits
+  virtual void alltoall(const torch::Tensor& input, torch::Tensor& output,
+                        const std::vector<int64_t>& input_split_sizes,
+                        const std::vector<int64_t>& output_split_sizes) const = 0;
+  // one group per device, created together (process_group.h:46-49)
+  static std::vector<std::unique_ptr<ProcessGroup>> create_process_groups(
+      const std::vector<torch::Device>& devices);
+
+ private:
+  int rank_ = 0, world_size_ = 0;
+  torch::Device device_;
+};
+
+// llm::ProcessGroupNCCL's contract over RCCL: one communicator per local GPU created together
 // (ncclCommInitAll, as process_group.cpp:98-123), collectives on the CURRENT stream of the
-// tensor's device so they are captured into hipGraphs with the kernels around them.
-class ProcessGroupRCCL {
+// tensor's device so they are captured into hipGraphs with the kernels around them; all-to-all as
+// grouped ncclSend / ncclRecv pairs (process_group.cpp:206-292).
+class ProcessGroupRCCL : public ProcessGroup {
  public:
   static std::vector<std::unique_ptr<ProcessGroupRCCL>> create_process_groups(
       const std::vector<torch::Device>& devices);
-  ~ProcessGroupRCCL();
-  int rank() const { return rank_; }
-  int world_size() const { return world_size_; }
-  void allreduce(torch::Tensor& input) const;
-  void allgather(const torch::Tensor& input, std::vector<torch::Tensor>& outputs) const;
-  void allgather(const torch::Tensor& input, torch::Tensor& outputs) const;
+  ~ProcessGroupRCCL() override;
+  void allreduce(torch::Tensor& input) const override;
+  void allgather(const torch::Tensor& input, std::vector<torch::Tensor>& outputs) const override;
+  void allgather(const torch::Tensor& input, torch::Tensor& outputs) const override;
+  void alltoall(const torch::Tensor& input, torch::Tensor& output) const override;
+  void alltoall(const torch::Tensor& input, torch::Tensor& output, const std::vector<int64_t>& input_split_sizes,
+                const std::vector<int64_t>& output_split_sizes) const override;
 
  private:
   ProcessGroupRCCL(int rank, int world_size, torch::Device device, void* comm)
-      : rank_(rank), world_size_(world_size), device_(device), comm_(comm) {}
-  int rank_, world_size_;
-  torch::Device device_;
+      : ProcessGroup(rank, world_size, device), comm_(comm) {}
   void* comm_;  // ncclComm_t
 };
 

@@ -85,3 +85,24 @@ def test_bench_70b_config_reduced_layers_runs_on_one_gpu():
     assert "gptq (symmetric)" in rec["config"]["workload"] and rec["config"]["reduced_model"] is True
     assert rec["int4_gemm"]["shape"] == [128, 8192, 57344]
     assert rec["cpu_baseline"] is None and rec["value"] > 0
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("world,model", [(4, "8b"), (8, "8b"), (8, "70b")])
+def test_bench_world_4_and_8_rehearsal_on_one_gpu(world, model):
+    """First contact for the driver's N = 4 / 8 runs, as far as one GPU allows (VERDICT r2 item 5 i):
+    the same torchrun command with all ranks on this GPU.  Exercises rank indexing at world > 2, one
+    KV head per rank at world 8 (both models have 8), the start-up probe (int4 GEMM writing the message
+    buffer, then the fused reduce, captured), the buffer alternation of the fused reduce over real
+    interprocess mappings at world 4 / 8, and the vocab-sharded greedy exchange.  Fused and collective reduce paths must give
+    identical tokens (both sum the `world` partials in fp32 in rank order)."""
+    margs = ("--model", model) if model != "8b" else ()
+    fused, err_f = _torchrun(world, {}, margs)
+    plain, _ = _torchrun(world, {"SLM_CUSTOM_AR": "0"}, margs)
+    for rec in (fused, plain):
+        assert rec["n_gpus"] == world and rec["config"]["parallelism"] == f"tp{world}"
+        assert rec["config"]["collectives"]["ranks"] == world and rec["value"] > 0
+        assert rec["config"]["model"] == model
+    assert "xgmi" in fused["config"]["row_parallel_reduce"], (fused["config"], err_f[-1500:])
+    tf, tp = fused["config"]["first_step_tokens"], plain["config"]["first_step_tokens"]
+    assert len(tf) == 8 and tf == tp, f"fused vs collective reduce disagree at world {world}: {tf} vs {tp}"

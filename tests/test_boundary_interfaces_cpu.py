@@ -97,6 +97,21 @@ def test_parallel_linear_interface_is_the_reference_one():
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is not mounted here")
+def test_process_group_interface_is_the_reference_one():
+    """slm::ProcessGroup (slm_torch_shim.h) against llm::ProcessGroup
+    (src/model_parallel/process_group.h:10-60): the five pure virtuals -- allreduce, both allgather
+    forms, both alltoall forms -- and the RCCL class derives from the abstract one."""
+    ref = _virtuals(_class_body(_read(os.path.join(REF, "model_parallel/process_group.h")), "ProcessGroup"))
+    text = _read(os.path.join(SHIM, "slm_torch_shim.h"))
+    ours = _virtuals(_class_body(text, "ProcessGroup"))
+    assert len(ref) == 5, ref
+    assert ours == ref, f"only in the reference: {ref - ours}\nonly in the shim: {ours - ref}"
+    assert re.search(r"class\s+ProcessGroupRCCL\s*:\s*public\s+ProcessGroup\b", text)
+    for accessor in ("rank", "world_size", "device", "create_process_groups"):
+        assert re.search(r"\b" + accessor + r"\s*\(", _class_body(text, "ProcessGroup")), accessor
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is not mounted here")
 def test_value_types_keep_the_reference_member_names():
     """slm::InputParameters / slm::KVCache restate models/parameters.h and memory/kv_cache.h: every
     data member / accessor the attention path uses must exist under the reference's name."""
