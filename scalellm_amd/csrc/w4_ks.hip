@@ -216,12 +216,16 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
       const int cabs = cw0 + c;
       // chunks past K: out-of-range loads write zeros (zero activations x clamped weights = 0)
       const uint32_t a_soff = (cabs <= clast && !(p.ks_dbg & 1)) ? (uint32_t)cabs * 256u : KS_OOB;
+      // rows >= M are never stored and MFMA rows are independent: their four-row DMA instructions are
+      // skipped (the staging memory then holds whatever was there -- any bit pattern is fine).  At
+      // M <= 4 that is 1/8 of the activation traffic and of the LDS fill, the bulk of the prologue.
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
-                     :
-                     : "v"(dma_voff[i]), "s"(stage_base(c & 1, i)), "s"(a_rs4), "s"(a_soff)
-                     : "memory");
+        if (4 * i < p.M)
+          asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                       :
+                       : "v"(dma_voff[i]), "s"(stage_base(c & 1, i)), "s"(a_rs4), "s"(a_soff)
+                       : "memory");
     };
     // fragment (row m = lane & 31, octet 2j + h) sits at row group m >> 2, row-in-group m & 3,
     // position (2j + h) ^ (m & 15) = 2j ^ ((m & 15) ^ h)
