@@ -1,5 +1,7 @@
 #!/bin/bash
 set -x
-timeout 600 python -m pytest tests/test_w4_gpu.py -m gpu -q -x 2>&1 | tail -3
-timeout 900 python tools/bench_small_gemm.py --m 1,2,4,8,16,32 --layer --check --rounds 7 --variants "AUTO;SLM_W4_GEMV=0;SLM_W4_KS=0,SLM_W4_GEMV=2" 2>&1 | grep -v amdgpu.ids | cut -c1-250
-timeout 900 python tools/bench_small_gemm.py --m 1 --check --rounds 7 --variants "AUTO;SLM_W4_GEMV=0" 2>&1 | grep -v amdgpu.ids | cut -c1-250
+R=$PWD
+export MS=32 N_LAUNCH=3
+bash tools/prof_summarize.sh r03_pmc_ks_a --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE -- python $R/tools/profile_gemm.py
+bash tools/prof_summarize.sh r03_pmc_ks_b --kernel-trace --pmc SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS -- python $R/tools/profile_gemm.py
+ls -la gpurun_out/r03_pmc_ks_a gpurun_out/r03_pmc_ks_b; tail -3 gpurun_out/r03_pmc_ks_a/run.log
