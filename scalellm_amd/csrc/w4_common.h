@@ -13,8 +13,84 @@ struct W4Dq;
 
 template <>
 struct W4Dq<bf16_tag> {
-  float s, c;
+  // bf16 has no packed VALU arithmetic on gfx950: the affine map runs in fp32 on the NIBBLE VALUES
+  // (q as a float straight out of v_cvt_f32_ubyteN, no shifts), fma(q, s, -z s) = (q - z) s exactly
+  // (<= 5 + 8 significant bits), one rounding in v_cvt_pk_bf16_f32.  Per 8-weight word: 3 mask /
+  // shift + 8 cvt + 4 v_pk_fma_f32 + 4 cvt_pk = 19 VALU (the magic-number route through fp32 took 27
+  // and produced the same bits).
+  f32x2 s2, c2;
+  struct Nib { uint32_t lo, hi; };  // lo: bytes (e0, e4, e1, e5); hi: bytes (e2, e6, e3, e7)
   __device__ __forceinline__ explicit W4Dq(uint32_t sz) {
+    const float s = __builtin_bit_cast(float, sz << 16);
+    const float zm = __builtin_bit_cast(float, sz & 0xffff0000u);  // 128 + zero, exact
+    const float c = -(zm - 128.0f) * s;                            // -zero * s: exact
+    s2 = f32x2{s, s};
+    c2 = f32x2{c, c};
+  }
+  __device__ __forceinline__ Nib split(uint32_t w) const {
+    Nib n;
+    n.lo = w & 0x0F0F0F0Fu;
+    n.hi = (w >> 4) & 0x0F0F0F0Fu;
+    // opaque: otherwise hipcc re-derives every nibble from w with its own shift + and
+    asm("" : "+v"(n.lo));
+    asm("" : "+v"(n.hi));
+    return n;
+  }
+  // nibble pair i (elements 2i, 2i+1) -> packed bf16 pair
+  __device__ __forceinline__ uint32_t pair(const Nib& n, int i) const {
+    const uint32_t src = (i & 1) ? n.hi : n.lo;
+    f32x2 q;
+    if (i < 2) q = f32x2{(float)(src & 0xffu), (float)((src >> 16) & 0xffu)};
+    else q = f32x2{(float)((src >> 8) & 0xffu), (float)(src >> 24)};
+    const f32x2 r = __builtin_elementwise_fma(q, s2, c2);
+    return pack2<bf16_tag>(r[0], r[1]);
+  }
+  // 8 nibbles -> 4 packed bf16 pairs, element order e = 0..7
+  __device__ __forceinline__ void word(uint32_t w, uint32_t (&out)[4]) const {
+    const Nib n = split(w);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = pair(n, i);
+  }
+};
+
+template <>
+struct W4Dq<f16_tag> {
+  f16x2_t s2, nzm2;
+  __device__ __forceinline__ explicit W4Dq(uint32_t sz) {
+    const f16x2_t v = __builtin_bit_cast(f16x2_t, sz);
+    s2 = f16x2_t{v[0], v[0]};
+    nzm2 = f16x2_t{-v[1], -v[1]};  // -(1024 + zero)
+  }
+  struct Nib { uint32_t w; };
+  __device__ __forceinline__ Nib split(uint32_t w) const { return Nib{w}; }
+  __device__ __forceinline__ uint32_t pair(const Nib& n, int i) const {
+    const uint32_t w = n.w;
+    const uint32_t t = ((w >> (4 * i)) & 0x000F000Fu) | 0x64006400u;  // (1024+q_lo, 1024+q_hi)
+    const f16x2_t d = __builtin_bit_cast(f16x2_t, t) + nzm2;          // q - z, exact
+    return __builtin_bit_cast(uint32_t, d * s2);                      // RN
+  }
+  __device__ __forceinline__ void word(uint32_t w, uint32_t (&out)[4]) const {
+    const Nib n = split(w);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = pair(n, i);
+  }
+};
+
+// The magic-number route through fp32 (128 + q as a bf16 bit pattern widened to fp32, then
+// fma(128 + q, s, -(128 + zero) s): 27 VALU per word, the same bits as W4Dq<bf16_tag>).  Kept for the
+// wave-specialised kernel (w4_ws.hip): its producers interleave the dequant with LDS-DMA issue, and
+// the short form measured 7 % SLOWER there (gate_up M = 256: 67.5 -> 72.2 us, A/B on one box).
+template <typename T>
+struct W4DqMagic : W4Dq<T> {
+  __device__ __forceinline__ explicit W4DqMagic(uint32_t sz) : W4Dq<T>(sz) {}
+  __device__ __forceinline__ uint32_t pair(uint32_t w, int i) const {
+    return W4Dq<T>::pair(W4Dq<T>::split(w), i);
+  }
+};
+template <>
+struct W4DqMagic<bf16_tag> {
+  float s, c;
+  __device__ __forceinline__ explicit W4DqMagic(uint32_t sz) {
     s = __builtin_bit_cast(float, sz << 16);
     const float zm = __builtin_bit_cast(float, sz & 0xffff0000u);  // 128 + zero, exact
     c = -zm * s;                                                    // <= 16 significant bits: exact
@@ -33,24 +109,6 @@ struct W4Dq<bf16_tag> {
   }
 };
 
-template <>
-struct W4Dq<f16_tag> {
-  f16x2_t s2, nzm2;
-  __device__ __forceinline__ explicit W4Dq(uint32_t sz) {
-    const f16x2_t v = __builtin_bit_cast(f16x2_t, sz);
-    s2 = f16x2_t{v[0], v[0]};
-    nzm2 = f16x2_t{-v[1], -v[1]};  // -(1024 + zero)
-  }
-  __device__ __forceinline__ uint32_t pair(uint32_t w, int i) const {
-    const uint32_t t = ((w >> (4 * i)) & 0x000F000Fu) | 0x64006400u;  // (1024+q_lo, 1024+q_hi)
-    const f16x2_t d = __builtin_bit_cast(f16x2_t, t) + nzm2;          // q - z, exact
-    return __builtin_bit_cast(uint32_t, d * s2);                      // RN
-  }
-  __device__ __forceinline__ void word(uint32_t w, uint32_t (&out)[4]) const {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) out[i] = pair(w, i);
-  }
-};
 
 // POST-scaled form (small-M kernels): the MFMA consumes the raw magic-number values (magic + q,
 // exact in T) -- unpack is 7 VALU per 8 weights instead of ~27 -- and the affine part is applied to

@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(512, 2) w4a16_gemm_ws_kernel(const GemmKParams
       const int cc = bu >> 1;  // its chunk (relative)
       const uint32_t keep = (bu >= 0 && cc < n) ? 0xffffffffu : 0u;  // tail / head units: zero fragments
       char* bdst = smem + WS_B_BASE + (bu & (WS_B_UNITS - 1)) * WS_B_UNIT + ((pw * 2 * 64 + lane) << 4);
-      const W4Dq<T> dq(szc[NGC == 2 ? half : 0]);
+      const W4DqMagic<T> dq(szc[NGC == 2 ? half : 0]);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const uint32_t word = half == 0 ? (j == 0 ? wv.x : wv.y) : (j == 0 ? wv.z : wv.w);
