@@ -354,9 +354,16 @@ def _probe_xgmi_main():
         gen = torch.Generator(device=dev).manual_seed(99)          # same weights and activations on every rank
         ck = _rand_int4_linear(gen, 256, hidden, 128, "awq", torch.bfloat16, dev)
         packed = K.awq_repack(ck["qweight"], ck["qzeros"], ck["scales"], 128)
-        x = torch.randn(bs, 256, device=dev, dtype=torch.bfloat16, generator=gen)
-        part = torch.empty(bs, hidden, device=dev, dtype=torch.bfloat16)
-        K.gptq_gemm(x, packed, part)                                 # (also sizes the workspace before capture)
+        # three DIFFERENT activations, one per replay: a peer that still saw the previous replay's
+        # partial sums (a stale line somewhere between the producer's L2 and the reader) would
+        # reproduce the previous result, not this one
+        xs = [torch.randn(bs, 256, device=dev, dtype=torch.bfloat16, generator=gen) for _ in range(3)]
+        parts = []
+        for xk in xs:
+            pk = torch.empty(bs, hidden, device=dev, dtype=torch.bfloat16)
+            K.gptq_gemm(xk, packed, pk)                              # (also sizes the workspace before capture)
+            parts.append(pk)
+        x = torch.empty_like(xs[0])
         w = torch.ones(hidden, device=dev, dtype=torch.bfloat16)
         res = torch.zeros(bs, hidden, device=dev, dtype=torch.bfloat16)
         out = torch.empty_like(res)
@@ -365,17 +372,18 @@ def _probe_xgmi_main():
             for i in (0, 1):
                 K.gptq_gemm(x, packed, ar.buffer(i, bs))
                 ar.allreduce_residual_rmsnorm(i, bs, out, res, w, 1e-5)
-        for _ in range(3):
+        own = ar.owned_rows(bs)
+        for xk, pk in zip(xs, parts):
+            x.copy_(xk)
             res.zero_()
             g.replay()
-        torch.cuda.synchronize()
-        own = ar.owned_rows(bs)
-        # every rank contributed the same partial p: residual = bf16(world p) after the first reduction,
-        # bf16(world p + that) after the second -- exact in fp32 for world <= 8, compared bit for bit
-        p32 = part.float() * world
-        r1 = p32.to(torch.bfloat16)
-        r2 = (p32 + r1.float()).to(torch.bfloat16)
-        ok = ar.error() == 0 and torch.equal(res[own.start:own.stop], r2[own.start:own.stop])
+            torch.cuda.synchronize()
+            # every rank contributed the same partial p: residual = bf16(world p) after the first reduction,
+            # bf16(world p + that) after the second -- exact in fp32 for world <= 8, compared bit for bit
+            p32 = pk.float() * world
+            r1 = p32.to(torch.bfloat16)
+            r2 = (p32 + r1.float()).to(torch.bfloat16)
+            ok = ok and ar.error() == 0 and torch.equal(res[own.start:own.stop], r2[own.start:own.stop])
     votes = [None] * world
     torch.distributed.all_gather_object(votes, bool(ok))
     if all(votes):
