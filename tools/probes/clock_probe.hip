@@ -71,6 +71,26 @@ __global__ void __launch_bounds__(512) mfma_loop_kernel(const uint32_t* seed, fl
   if (r == 12345.678f) sink[0] = r;
 }
 
+
+// read-only HBM stream: every wave walks its own contiguous region 1 KiB per instruction, DEPTH loads
+// in flight per lane (nt: touched once), xor-folded so nothing is optimised away
+template <int DEPTH>
+__global__ void __launch_bounds__(512) read_stream_kernel(const uint32_t* src, size_t words_per_wave, uint32_t* sink) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const size_t wave = (size_t)blockIdx.x * 8 + (threadIdx.x >> 6);
+  const u32x4* p = reinterpret_cast<const u32x4*>(src + wave * words_per_wave) + (threadIdx.x & 63);
+  const size_t n = words_per_wave / 256;  // 1-KiB steps
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  for (size_t i = 0; i + DEPTH <= n; i += DEPTH) {
+    u32x4 v[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) v[d] = __builtin_nontemporal_load(p + (i + d) * 64);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) acc ^= v[d];
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = acc.x;
+}
+
 struct Stats {
   double mhz_med, mhz_min, mhz_max, window_us;
   int n;
@@ -167,6 +187,25 @@ int main() {
              mfma_flop / 1e6, "tflops", [&](hipStream_t st) {
                hipLaunchKernelGGL(mfma_loop_kernel, dim3(2048), dim3(512), 0, st, dseed, sink, iters);
              }, 1, 6);
+  }
+
+
+  // ---- HBM read stream: 8 GiB walked once per launch (far beyond the 256 MiB Infinity Cache)
+  {
+    const size_t bytes = (size_t)8 << 30;
+    uint32_t* src;
+    CK(hipMalloc(&src, bytes));
+    CK(hipMemset(src, 1, bytes));
+    for (int wgs : {256, 512, 1024, 2048}) {
+      const size_t waves = (size_t)wgs * 8;
+      const size_t words_per_wave = bytes / 4 / waves;
+      char name[128];
+      snprintf(name, sizeof(name), "read-only stream 8 GiB, %d workgroups x 8 waves, 8 x 16 B in flight per lane", wgs);
+      run_load(name, (double)bytes / 1e6, "tbps", [&](hipStream_t st) {
+        hipLaunchKernelGGL(read_stream_kernel<8>, dim3(wgs), dim3(512), 0, st, src, words_per_wave, (uint32_t*)sink);
+      }, 1, 8);
+    }
+    CK(hipFree(src));
   }
 
   // ---- HBM stream: device-to-device copy of 1 GiB
