@@ -169,7 +169,12 @@ SLM_API int slm_set_kv_cache(const int32_t* slot_ids,  /* [n_tokens]           *
 /*           with K = the padded row count, group_size = 32 and one scale row */
 /*           per 32-row block (tools: kernels.gptq_repack / slm::W4Linear).   */
 /* ========================================================================== */
-typedef enum slm_w4_format { SLM_W4_GPTQ = 0, SLM_W4_AWQ = 1 } slm_w4_format;
+typedef enum slm_w4_format {
+  SLM_W4_GPTQ = 0,
+  SLM_W4_AWQ = 1,
+  SLM_W8_GPTQ = 2, /* 8-bit checkpoints: slm_w8_prepack_* only (section 3b) */
+  SLM_W8_AWQ = 3
+} slm_w4_format;
 #define SLM_W4_FORMAT_MASK 0xF
 /* OR into `format`: the checkpoint tensors are a merged [gate | up] column-parallel weight (the
  * reference builds it by concatenating gate_proj and up_proj along N,
@@ -200,6 +205,37 @@ SLM_API int slm_w4_prepack_weights(int32_t format, const int32_t* qweight, const
 SLM_API int slm_w4_prepack_sz(int32_t format, const int32_t* qzeros /* or NULL */, const void* scales,
                               int64_t K, int64_t N, int64_t group_size, int32_t dtype, void* sz_out,
                               void* stream);
+
+/* ========================================================================== */
+/* 3b. 8-bit weights (num_bits = 8 of marlin::gptq_gemm / gptq_repack /        */
+/*     awq_repack, marlin.h:17-37; bits = 8 of the quantised linears,          */
+/*     qlinear_awq_marlin_impl.cpp:25-26; CPU semantics construct_weights,     */
+/*     qlinear_impl.cpp:21-100) as TWO int4 planes of the int4 GEMM:           */
+/*       s (q - z) = (16 s)(hi - zh) + s (lo - zl),  q = 16 hi + lo            */
+/*     The packed weight has 2K rows -- [0, K) high nibbles (scale 16 s,       */
+/*     zero z >> 4), [K, 2K) low nibbles (scale s, zero z & 15) -- and the     */
+/*     GEMM reads the activations twice through its column gather:            */
+/*       slm_w4_gemm_args { K = 2K, lda = the real row stride of A,            */
+/*                          perm = perm2 (written by slm_w8_prepack_weights),  */
+/*                          group_size = slm_w8_packed_group_size(K, g) }      */
+/*     Exact in exact arithmetic; same HBM bytes as a native 8-bit kernel,     */
+/*     twice the MFMA work of an int4 GEMM (csrc/w8_planes.hip).               */
+/*     Checkpoint layouts: GPTQ qweight [K/4, N] (byte k%4), qzeros [G, N/4]   */
+/*     (byte n%4, zero = stored + 1), AWQ qweight [K, N/4] / qzeros [G, N/4]   */
+/*     with the byte order [0,2,1,3] (tests/kernels/quant_utils.py:182-184).   */
+/*     Sizes: slm_w4_packed_weight_bytes(2K, N),                               */
+/*            slm_w4_packed_sz_bytes(2K, N, packed group size), perm2 [2K].    */
+/* ========================================================================== */
+SLM_API int64_t slm_w8_packed_rows(int64_t K);
+SLM_API int64_t slm_w8_packed_group_size(int64_t K, int64_t group_size); /* 0 = unsupported */
+SLM_API int slm_w8_prepack_weights(int32_t format, /* SLM_W8_* (| SLM_W4_PAIRED) */
+                                   const int32_t* qweight,
+                                   const int32_t* perm, /* [K] act-order sorted-row -> ckpt-row, or NULL */
+                                   int64_t K, int64_t N, void* wq_out, int32_t* perm2_out /* [2K] */,
+                                   void* stream);
+SLM_API int slm_w8_prepack_sz(int32_t format, const int32_t* qzeros /* or NULL: symmetric, zero 128 */,
+                              const void* scales /* [K / group_size, N] T */, int64_t K, int64_t N,
+                              int64_t group_size, int32_t dtype, void* sz_out, void* stream);
 
 /* ========================================================================== */
 /* 4. int4-weight x fp16/bf16-activation GEMM  C[M,N] = A[M,K] . dequant(W)   */

@@ -134,7 +134,9 @@ def combine(o_part, ml) -> np.ndarray:
     return out
 
 
-def gptq_dequant(qweight, qzeros, scales, group_size: int, g_idx=None) -> np.ndarray:
+def gptq_dequant(qweight, qzeros, scales, group_size: int, g_idx=None, bits: int = 4) -> np.ndarray:
+    if bits != 4:
+        return gptq_dequant_bits(qweight, qzeros, scales, group_size, g_idx, bits)
     qw, qz, sc = _i32(qweight), _i32(qzeros), _f32(scales)
     K, N = qw.shape[0] * 8, qw.shape[1]
     gi = _i32(g_idx) if g_idx is not None and len(g_idx) else None
@@ -145,7 +147,35 @@ def gptq_dequant(qweight, qzeros, scales, group_size: int, g_idx=None) -> np.nda
     return out
 
 
-def awq_dequant(qweight, qzeros, scales, group_size: int) -> np.ndarray:
+def gptq_dequant_bits(qweight, qzeros, scales, group_size: int, g_idx=None, bits: int = 8) -> np.ndarray:
+    """construct_weights for any bit width (qlinear_impl.cpp:21-57); qzeros None = symmetric."""
+    qw, sc = _i32(qweight), _f32(scales)
+    qz = _i32(qzeros) if qzeros is not None else None
+    K, N = qw.shape[0] * (32 // bits), qw.shape[1]
+    gi = _i32(g_idx) if g_idx is not None and len(g_idx) else None
+    out = np.empty((K, N), dtype=np.float32)
+    f = lib().oracle_gptq_dequant_bits
+    f.restype = None
+    f(_p(qw, _i32p), _p(qz, _i32p) if qz is not None else None, _p(sc, _f32p),
+      _p(gi, _i32p) if gi is not None else None, C.c_int64(K), C.c_int64(N), C.c_int64(group_size),
+      C.c_int32(bits), _p(out, _f32p))
+    return out
+
+
+def awq_dequant_bits(qweight, qzeros, scales, group_size: int, bits: int = 8) -> np.ndarray:
+    qw, qz, sc = _i32(qweight), _i32(qzeros), _f32(scales)
+    K, N = qw.shape[0], qw.shape[1] * (32 // bits)
+    out = np.empty((K, N), dtype=np.float32)
+    f = lib().oracle_awq_dequant_bits
+    f.restype = None
+    f(_p(qw, _i32p), _p(qz, _i32p), _p(sc, _f32p), C.c_int64(K), C.c_int64(N), C.c_int64(group_size),
+      C.c_int32(bits), _p(out, _f32p))
+    return out
+
+
+def awq_dequant(qweight, qzeros, scales, group_size: int, bits: int = 4) -> np.ndarray:
+    if bits != 4:
+        return awq_dequant_bits(qweight, qzeros, scales, group_size, bits)
     qw, qz, sc = _i32(qweight), _i32(qzeros), _f32(scales)
     K, N = qw.shape[0], qw.shape[1] * 8
     out = np.empty((K, N), dtype=np.float32)

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libslm_hip.so")
 
 SLM_F16, SLM_BF16 = 0, 1
 SLM_W4_GPTQ, SLM_W4_AWQ = 0, 1
+SLM_W8_GPTQ, SLM_W8_AWQ = 2, 3  # 8-bit checkpoints: slm_w8_prepack_* (two int4 planes)
 SLM_W4_PAIRED = 0x10
 
 
@@ -119,6 +120,13 @@ def lib() -> C.CDLL:
         ("slm_w4_prepack_weights", C.c_int,
          [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
         ("slm_w4_prepack_sz", C.c_int,
+         [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
+          C.c_void_p]),
+        ("slm_w8_packed_rows", C.c_int64, [C.c_int64]),
+        ("slm_w8_packed_group_size", C.c_int64, [C.c_int64, C.c_int64]),
+        ("slm_w8_prepack_weights", C.c_int,
+         [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+        ("slm_w8_prepack_sz", C.c_int,
          [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_void_p,
           C.c_void_p]),
         ("slm_w4a16_gemm_workspace_bytes", C.c_size_t, [C.POINTER(W4GemmArgs)]),

@@ -376,25 +376,73 @@ def _prepack(fmt: int, qweight, qzeros, scales, perm, K, N, group_size, paired=F
 def awq_repack(qweight: torch.Tensor,  # [K, N/8] int32, AWQ interleave
                qzeros: torch.Tensor,   # [G, N/8] int32, AWQ interleave
                scales: torch.Tensor,   # [G, N] fp16/bf16
-               group_size: int, paired: bool = False) -> PackedW4:
+               group_size: int, paired: bool = False, bits: int = 4) -> PackedW4:
     """Mirror of marlin::awq_repack (+ the host-side zero/scale permutes of
     qlinear_awq_marlin_impl.cpp:34-125), from the AWQ checkpoint format.
 
     paired: the tensors are a merged [gate | up] weight (multi_parallel_linear.cpp:14-41); pack
-    the two halves interleaved by 32-column tile so the GEMM can fuse SiLU*mul (silu_mul=True)."""
+    the two halves interleaved by 32-column tile so the GEMM can fuse SiLU*mul (silu_mul=True).
+    bits = 8: qweight [K, N/4], qzeros [G, N/4] (byte order [0,2,1,3]); packed as two int4 planes
+    (include/slm_hip.h section 3b)."""
+    if bits == 8:
+        K, N = qweight.size(0), qweight.size(1) * 4
+        return _prepack8(_lib.SLM_W8_AWQ, qweight, qzeros, scales, None, K, N, group_size, paired)
+    if bits != 4:
+        raise SlmError(f"awq_repack: bits must be 4 or 8, got {bits}")
     K, N = qweight.size(0), qweight.size(1) * 8
     return _prepack(_lib.SLM_W4_AWQ, qweight, qzeros, scales, None, K, N, group_size, paired)
+
+
+def _prepack8(fmt: int, qweight, qzeros, scales, perm, K, N, group_size, paired=False) -> PackedW4:
+    """8-bit checkpoint -> two int4 planes over 2K packed rows + the doubled activation gather
+    (csrc/w8_planes.hip).  qzeros may be None (symmetric, zero = 128)."""
+    L = _lib.lib()
+    _require_gpu(qweight, qzeros, scales, perm)
+    for t in (qweight, qzeros):
+        if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
+            raise SlmError("qweight / qzeros must be contiguous int32")
+    if not scales.is_contiguous():
+        raise SlmError("scales must be contiguous [n_groups, N]")
+    gs = K if group_size in (-1, 0) else int(group_size)
+    if K % gs or tuple(scales.shape) != (K // gs, N) or \
+            (qzeros is not None and tuple(qzeros.shape) != (K // gs, N // 4)):
+        raise SlmError(f"scales/qzeros shapes do not match K={K} N={N} group_size={gs} (8-bit)")
+    gp = L.slm_w8_packed_group_size(K, gs)
+    K2 = L.slm_w8_packed_rows(K)
+    nb_w = L.slm_w4_packed_weight_bytes(K2, N)
+    nb_sz = L.slm_w4_packed_sz_bytes(K2, N, gp) if gp > 0 else 0
+    if gp <= 0 or nb_w == 0 or nb_sz == 0:
+        raise SlmError(f"unsupported 8-bit shape K={K} N={N} group_size={gs} (need K%64, N%32, "
+                       f"group 32 / 64 / a multiple of 128)")
+    if perm is not None and (perm.dtype != torch.int32 or not perm.is_contiguous()):
+        raise SlmError("perm must be contiguous int32 [K]")
+    if paired:
+        if N % 64:
+            raise SlmError(f"paired (gate | up) prepack needs N % 64 == 0, got N={N}")
+        fmt |= _lib.SLM_W4_PAIRED
+    dev = qweight.device
+    wq = torch.empty(nb_w // 4, dtype=torch.int32, device=dev)
+    sz = torch.empty(nb_sz // 4, dtype=torch.int32, device=dev)
+    perm2 = torch.empty(K2, dtype=torch.int32, device=dev)
+    check(L.slm_w8_prepack_weights(fmt, qweight.data_ptr(), perm.data_ptr() if perm is not None else None,
+                                   K, N, wq.data_ptr(), perm2.data_ptr(), _stream()), "slm_w8_prepack_weights")
+    check(L.slm_w8_prepack_sz(fmt, qzeros.data_ptr() if qzeros is not None else None, scales.data_ptr(),
+                              K, N, gs, _dtype_code(scales), sz.data_ptr(), _stream()), "slm_w8_prepack_sz")
+    return PackedW4(wq, sz, perm2, K2, N, gp, scales.dtype, paired, k_src=K)
 
 
 def gptq_repack(qweight: torch.Tensor,  # [K/8, N] int32
                 qzeros: torch.Tensor,   # [G, N/8] int32 (zero = stored + 1)
                 scales: torch.Tensor,   # [G, N]
                 group_size: int,
-                g_idx: Optional[torch.Tensor] = None, paired: bool = False) -> PackedW4:
+                g_idx: Optional[torch.Tensor] = None, paired: bool = False, bits: int = 4) -> PackedW4:
     """Mirror of marlin::gptq_repack (+ qlinear_gptq_marlin_impl.cpp:41-71): act-order
     checkpoints (g_idx not monotone) are handled like the reference: rows sorted by group
-    (perm = argsort(g_idx)), the activation columns gathered by the same perm at GEMM time."""
-    K, N = qweight.size(0) * 8, qweight.size(1)
+    (perm = argsort(g_idx)), the activation columns gathered by the same perm at GEMM time.
+    bits = 8: qweight [K/4, N], qzeros [G, N/4] (or None: symmetric); two int4 planes (slm_hip.h 3b)."""
+    if bits not in (4, 8):
+        raise SlmError(f"gptq_repack: bits must be 4 or 8, got {bits}")
+    K, N = qweight.size(0) * (32 // bits), qweight.size(1)
     gs = K if group_size in (-1, 0) else int(group_size)
     perm = None
     if g_idx is not None and g_idx.numel() > 0:
@@ -407,9 +455,13 @@ def gptq_repack(qweight: torch.Tensor,  # [K/8, N] int32
                 # uneven groups after sorting: a row-parallel shard of an act-order checkpoint
                 # (sharded qweight / g_idx, FULL scales: qlinear_gptq_marlin_impl.cpp:236-243,270-276;
                 # the reference then runs Marlin with is_k_full = false, :319)
+                if bits != 4:
+                    raise SlmError("act-order shards with uneven groups are supported for 4-bit weights only")
                 return _prepack_uneven_groups(qweight, qzeros, scales, g_idx.to(torch.int64), perm64,
                                               K, N, gs, paired)
             perm = perm64.to(torch.int32).contiguous()
+    if bits == 8:
+        return _prepack8(_lib.SLM_W8_GPTQ, qweight, qzeros, scales, perm, K, N, gs, paired)
     return _prepack(_lib.SLM_W4_GPTQ, qweight, qzeros, scales, perm, K, N, gs, paired)
 
 

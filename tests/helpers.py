@@ -184,3 +184,78 @@ def pack_case(case, bits="bf16", device="cuda", paired=False):
         return kernels.awq_repack(qweight, qzeros, scales, case["group_size"], paired=paired)
     g_idx = torch.from_numpy(case["g_idx"]).to(device) if case["g_idx"] is not None else None
     return kernels.gptq_repack(qweight, qzeros, scales, case["group_size"], g_idx, paired=paired)
+
+
+# ---- 8-bit checkpoints (num_bits = 8: quant_utils.py pack_rows / pack_cols / pack_awq_weights) ----
+AWQ_ORDER8 = [0, 2, 1, 3]
+
+
+def pack_rows8(q: np.ndarray) -> np.ndarray:
+    """[K, N] ints in 0..255 -> [K/4, N] int32, byte (k % 4) (GPTQ qweight, 8 bits)."""
+    q = q.astype(np.uint32)
+    out = np.zeros((q.shape[0] // 4, q.shape[1]), dtype=np.uint32)
+    for i in range(4):
+        out |= q[i::4, :] << (8 * i)
+    return out.view(np.int32)
+
+
+def pack_cols8(q: np.ndarray) -> np.ndarray:
+    q = q.astype(np.uint32)
+    out = np.zeros((q.shape[0], q.shape[1] // 4), dtype=np.uint32)
+    for i in range(4):
+        out |= q[:, i::4] << (8 * i)
+    return out.view(np.int32)
+
+
+def pack_awq8(q: np.ndarray) -> np.ndarray:
+    r, n = q.shape
+    return pack_cols8(q.reshape(-1, 4)[:, AWQ_ORDER8].reshape(r, n))
+
+
+def make_quant8_case(seed, K, N, group_size, fmt, dtype_bits="bf16", act_order=False, sym=False):
+    """Random 8-bit layer in checkpoint format (the int4 maker's twin).  sym: no zero-point tensor
+    (zero = 128, Marlin has_zp = false)."""
+    rng = np.random.default_rng(seed)
+    gs = K if group_size in (-1, 0) else group_size
+    G = K // gs
+    q = rng.integers(0, 256, size=(K, N)).astype(np.int32)
+    s = rng.uniform(0.0004, 0.0015, size=(G, N)).astype(np.float32)
+    if dtype_bits == "bf16":
+        s_bits = f32_to_bf16_bits(s)
+        s = bf16_bits_to_f32(s_bits)
+    else:
+        s_bits = s.astype(np.float16).view(np.uint16)
+        s = s_bits.view(np.float16).astype(np.float32)
+    g_idx = None
+    if fmt == "awq":
+        z = rng.integers(0, 256, size=(G, N)).astype(np.int32)
+        d = dict(qweight=pack_awq8(q), qzeros=pack_awq8(z), z_eff=z)
+    else:
+        z_stored = rng.integers(0, 256, size=(G, N)).astype(np.int32)
+        z_stored.flat[:4] = [0, 255, 15, 16]  # zero = 1, 256, 16, 17: both plane boundaries
+        if act_order:
+            g_idx = (np.arange(K) // gs)[rng.permutation(K)].astype(np.int32)
+        d = dict(qweight=pack_rows8(q), qzeros=None if sym else pack_cols8(z_stored),
+                 z_eff=np.full((G, N), 128, np.int32) if sym else z_stored + 1)
+    d.update(q=q, scales=s, scales_bits=s_bits, g_idx=g_idx, K=K, N=N, group_size=gs, fmt=fmt, bits=8)
+    return d
+
+
+def pack_case8(case, bits="bf16", device="cuda", paired=False):
+    import torch
+    from scalellm_amd import kernels
+    dt = torch.bfloat16 if bits == "bf16" else torch.float16
+    qweight = torch.from_numpy(case["qweight"]).to(device)
+    qzeros = torch.from_numpy(case["qzeros"]).to(device) if case["qzeros"] is not None else None
+    scales = torch.from_numpy(case["scales_bits"].view(np.int16)).to(device).view(dt)
+    if case["fmt"] == "awq":
+        return kernels.awq_repack(qweight, qzeros, scales, case["group_size"], paired=paired, bits=8)
+    g_idx = torch.from_numpy(case["g_idx"]).to(device) if case["g_idx"] is not None else None
+    return kernels.gptq_repack(qweight, qzeros, scales, case["group_size"], g_idx, paired=paired, bits=8)
+
+
+def dense_weight8(case) -> np.ndarray:
+    """fp32 (q - z) * s of a make_quant8_case() layer, in checkpoint row order (integer truth, no oracle)."""
+    K, gs = case["K"], case["group_size"]
+    gi = case["g_idx"] if case["g_idx"] is not None else np.arange(K) // gs
+    return case["scales"][gi] * (case["q"] - case["z_eff"][gi]).astype(np.float32)

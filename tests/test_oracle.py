@@ -146,6 +146,50 @@ def test_numpy_packers_match_reference_format():
             np.testing.assert_array_equal(w.astype(np.float32), c["w"])
 
 
+QUANT8 = helpers.load_npz_groups("quant8_cases.npz")
+
+
+@pytest.mark.parametrize("name", sorted(QUANT8))
+def test_8bit_dequant_matches_reference_python(name):
+    """num_bits = 8 (construct_weights is generic in bits: qlinear_impl.cpp:21-57) against tensors
+    packed by the reference's quant_utils helpers; the numpy 8-bit packers of tests/helpers.py are
+    pinned on the same tensors."""
+    c = QUANT8[name]
+    gs = int(c["group_size"][0])
+    sc = c["scales"].astype(np.float32)
+    if name.startswith("awq"):
+        w = oracle.awq_dequant(c["qweight"], c["qzeros"], sc, gs, bits=8)
+        u = c["qweight"].view(np.uint32)
+        q = np.stack([(u >> (8 * i)) & 0xFF for i in range(4)], axis=-1).reshape(u.shape[0], -1)  # packed order
+        inv = np.argsort(helpers.AWQ_ORDER8)
+        q = q.reshape(-1, 4)[:, inv].reshape(q.shape)
+        assert np.array_equal(helpers.pack_awq8(q), c["qweight"])
+    else:
+        g_idx = c["g_idx"] if int(c["act_order"][0]) else None
+        w = oracle.gptq_dequant(c["qweight"], c["qzeros"], sc, gs, g_idx, bits=8)
+        u = c["qweight"].view(np.uint32)
+        q = np.zeros((u.shape[0] * 4, u.shape[1]), np.int32)
+        for i in range(4):
+            q[i::4] = (u >> (8 * i)) & 0xFF
+        assert np.array_equal(helpers.pack_rows8(q), c["qweight"])
+        if name != "gptq8_asym":  # symmetric cases: the same weights with NO zero-point tensor (zero = 128)
+            np.testing.assert_array_equal(oracle.gptq_dequant(c["qweight"], None, sc, gs, g_idx, bits=8), w)
+    np.testing.assert_array_equal(w, c["w"])
+
+
+def test_4bit_entry_points_agree_with_the_generic_ones():
+    for name, c in QUANT.items():
+        gs = int(c["group_size"][0])
+        sc = c["scales"].astype(np.float32)
+        if name.startswith("awq"):
+            np.testing.assert_array_equal(oracle.awq_dequant_bits(c["qweight"], c["qzeros"], sc, gs, bits=4),
+                                          oracle.awq_dequant(c["qweight"], c["qzeros"], sc, gs))
+        else:
+            g_idx = c["g_idx"] if int(c["act_order"][0]) else None
+            np.testing.assert_array_equal(oracle.gptq_dequant_bits(c["qweight"], c["qzeros"], sc, gs, g_idx, bits=4),
+                                          oracle.gptq_dequant(c["qweight"], c["qzeros"], sc, gs, g_idx))
+
+
 def test_decode_advance_matches_a_full_host_rebuild():
     """f4: the incremental next-step inputs equal what the reference rebuilds from scratch every
     step (Batch::prepare_model_input, engine/batch.cpp:97-255): positions = tokens cached, slot =
