@@ -44,14 +44,14 @@ bool iequals(std::string a, const char* b) {
 bool is_awq(const QuantArgs& qa) { return iequals(qa.quant_method(), "awq") || iequals(qa.quant_method(), "gemm"); }
 
 // check_awq_quant_args / check_gptq_quant_args (qlinear_awq_marlin_impl.cpp:21-32,
-// qlinear_gptq_marlin_impl.cpp:18-29).  8-bit weights are the reference's int8 Marlin path: out of
-// this hot path's scope, refused loudly.  GPTQ: the reference's Marlin impl requires is_sym; these
-// kernels also take stored zero points, so asymmetric GPTQ checkpoints load as well.
+// qlinear_gptq_marlin_impl.cpp:18-29): 4 and 8 bits, as the reference.  GPTQ: the reference's
+// Marlin impl requires is_sym; these kernels also take stored zero points, so asymmetric GPTQ
+// checkpoints load as well.
 void check_quant_args(const QuantArgs& qa) {
   const bool awq = is_awq(qa);
   TORCH_CHECK(awq || iequals(qa.quant_method(), "gptq"), "Unsupported quant method: ", qa.quant_method());
   if (awq) TORCH_CHECK(qa.zero_point() && !qa.is_sym(), "Only zero_point is supported for AWQ");
-  TORCH_CHECK(qa.bits() == 4, "Only 4-bit weights are supported on the HIP int4 path, got bits = ", qa.bits());
+  TORCH_CHECK(qa.bits() == 4 || qa.bits() == 8, "Only 4 and 8 bits are supported, got bits = ", qa.bits());
   const auto gs = qa.group_size();
   TORCH_CHECK(gs == -1 || gs == 32 || gs == 64 || gs == 128,
               "Only group_size of -1, 32, 64, 128 are supported, got ", gs);
@@ -115,15 +115,16 @@ void QLinearHipBase::verify_loaded_weights(const std::string& prefix) const {
 torch::Tensor QLinearHipBase::gemm(const torch::Tensor& input, const std::optional<torch::Tensor>& bias) {
   if (!packed_) {  // repack at the first call, like the reference (weight_repacked_)
     verify_loaded_weights();
-    const int64_t K = awq_ ? qweight_.size(0) : qweight_.size(0) * 8;
-    const int64_t N = awq_ ? qweight_.size(1) * 8 : qweight_.size(1);
+    const int64_t per = 32 / quant_args_.bits();  // values per int32
+    const int64_t K = awq_ ? qweight_.size(0) : qweight_.size(0) * per;
+    const int64_t N = awq_ ? qweight_.size(1) * per : qweight_.size(1);
     TORCH_CHECK(K == local_in_ && N == local_out_, "loaded qweight is [", K, ", ", N, "], expected [",
                 local_in_, ", ", local_out_, "]");
     const int64_t gs = quant_args_.group_size() > 0 ? quant_args_.group_size() : K;
     std::optional<torch::Tensor> gi;
     if (g_idx_.defined() && g_idx_.numel() > 0) gi = g_idx_;
     packed_ = std::make_unique<W4Linear>(awq_ ? "awq" : "gptq", qweight_, qzeros_,
-                                         scales_.to(options_.dtype()), gi, gs);
+                                         scales_.to(options_.dtype()), gi, gs, quant_args_.bits());
     // the checkpoint-format shards are no longer needed
     qweight_ = torch::Tensor(); qzeros_ = torch::Tensor(); scales_ = torch::Tensor(); g_idx_ = torch::Tensor();
     if (has_bias_) bias_ = bias_.to(options_.dtype()).contiguous();

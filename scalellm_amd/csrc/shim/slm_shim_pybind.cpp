@@ -164,7 +164,9 @@ PYBIND11_MODULE(_slm_shim, m) {
         });
   py::class_<slm::W4Linear>(m, "W4Linear")
       .def(py::init<const std::string&, const torch::Tensor&, const torch::Tensor&,
-                    const torch::Tensor&, const std::optional<torch::Tensor>&, int64_t>())
+                    const torch::Tensor&, const std::optional<torch::Tensor>&, int64_t, int64_t>(),
+           py::arg("quant_method"), py::arg("qweight"), py::arg("qzeros"), py::arg("scales"),
+           py::arg("g_idx"), py::arg("group_size"), py::arg("bits") = 4)
       .def("forward", &slm::W4Linear::forward, py::arg("input"), py::arg("bias") = std::nullopt,
            py::arg("out") = std::nullopt)
       .def("dequantize", &slm::W4Linear::dequantize);

@@ -283,24 +283,38 @@ bool sorted_groups_are_whole(const torch::Tensor& g_idx, int64_t K, int64_t G) {
 
 void check_repack_args(const torch::Tensor& q_weight, const torch::Tensor& out, int64_t num_bits, int64_t K,
                        int64_t N) {
-  TORCH_CHECK(num_bits == 4, "only 4-bit weights are supported on the HIP int4 path, got ", num_bits);
+  TORCH_CHECK(num_bits == 4 || num_bits == 8, "num_bits must be 4 or 8, got ", num_bits);
   TORCH_CHECK(q_weight.is_cuda() && q_weight.is_contiguous() && q_weight.scalar_type() == torch::kInt);
+  // marlin repack output: [K/16, N*16/pack_factor] int32 (gptq_repack.cu / awq_repack.cu), pack_factor = 32/bits
   TORCH_CHECK(out.is_cuda() && out.is_contiguous() && out.scalar_type() == torch::kInt &&
-              out.numel() == K * N / 8, "out must be int32 [K/16, N*16/8]");
-  TORCH_CHECK(slm_w4_packed_weight_bytes(K, N) == static_cast<size_t>(K * N / 2),
-              "unsupported int4 shape K=", K, " N=", N, " (need K % 64 == 0, N % 32 == 0)");
+              out.numel() == K * N / (32 / num_bits), "out must be int32 [K/16, N*16/pack_factor]");
+  // 8 bits: two int4 planes over 2K packed rows (include/slm_hip.h section 3b) = the same byte count
+  const int64_t Kp = num_bits == 8 ? 2 * K : K;
+  TORCH_CHECK(slm_w4_packed_weight_bytes(Kp, N) == static_cast<size_t>(Kp * N / 2),
+              "unsupported shape K=", K, " N=", N, " (need K % 64 == 0, N % 32 == 0)");
 }
 }  // namespace
 
 void gptq_repack(const torch::Tensor& q_weight, const torch::Tensor& perm, torch::Tensor& out,
                  int64_t num_bits) {
-  const int64_t K = q_weight.size(0) * 8, N = q_weight.size(1);
+  TORCH_CHECK(num_bits == 4 || num_bits == 8, "num_bits must be 4 or 8, got ", num_bits);
+  const int64_t K = q_weight.size(0) * (32 / num_bits), N = q_weight.size(1);
   check_repack_args(q_weight, out, num_bits, K, N);
   const bool has_perm = perm.defined() && perm.numel() > 0;
   if (has_perm)
     TORCH_CHECK(perm.numel() == K && perm.scalar_type() == torch::kInt && perm.is_contiguous(),
                 "perm must be contiguous int32 [K]");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(q_weight.device());
+  if (num_bits == 8) {
+    // the doubled activation gather is rebuilt (and cached) by gptq_gemm from `perm`: this signature
+    // has nowhere to return it
+    auto perm2 = torch::empty({2 * K}, torch::dtype(torch::kInt).device(q_weight.device()));
+    check(slm_w8_prepack_weights(SLM_W8_GPTQ, q_weight.const_data_ptr<int32_t>(),
+                                 has_perm ? perm.const_data_ptr<int32_t>() : nullptr, K, N, out.mutable_data_ptr(),
+                                 perm2.mutable_data_ptr<int32_t>(), current_stream(q_weight)),
+          "slm_w8_prepack_weights");
+    return;
+  }
   check(slm_w4_prepack_weights(SLM_W4_GPTQ, q_weight.const_data_ptr<int32_t>(),
                                has_perm ? perm.const_data_ptr<int32_t>() : nullptr, K, N,
                                out.mutable_data_ptr(), current_stream(q_weight)),
@@ -308,9 +322,17 @@ void gptq_repack(const torch::Tensor& q_weight, const torch::Tensor& perm, torch
 }
 
 void awq_repack(const torch::Tensor& q_weight, torch::Tensor& out, int64_t num_bits) {
-  const int64_t K = q_weight.size(0), N = q_weight.size(1) * 8;
+  TORCH_CHECK(num_bits == 4 || num_bits == 8, "num_bits must be 4 or 8, got ", num_bits);
+  const int64_t K = q_weight.size(0), N = q_weight.size(1) * (32 / num_bits);
   check_repack_args(q_weight, out, num_bits, K, N);
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(q_weight.device());
+  if (num_bits == 8) {
+    auto perm2 = torch::empty({2 * K}, torch::dtype(torch::kInt).device(q_weight.device()));
+    check(slm_w8_prepack_weights(SLM_W8_AWQ, q_weight.const_data_ptr<int32_t>(), nullptr, K, N,
+                                 out.mutable_data_ptr(), perm2.mutable_data_ptr<int32_t>(), current_stream(q_weight)),
+          "slm_w8_prepack_weights");
+    return;
+  }
   check(slm_w4_prepack_weights(SLM_W4_AWQ, q_weight.const_data_ptr<int32_t>(), nullptr, K, N,
                                out.mutable_data_ptr(), current_stream(q_weight)),
         "slm_w4_prepack_weights");
@@ -320,7 +342,8 @@ void gptq_gemm(const torch::Tensor& A, const torch::Tensor& B, torch::Tensor& C,
                const torch::Tensor& scales, const torch::Tensor& zeros, const torch::Tensor& g_idx,
                const torch::Tensor& perm, torch::Tensor& /*workspace*/, int num_bits, bool is_k_full,
                bool has_zp, bool /*use_fp32_reduce*/) {
-  TORCH_CHECK(num_bits == 4, "only 4-bit weights are supported on the HIP int4 path, got ", num_bits);
+  TORCH_CHECK(num_bits == 4 || num_bits == 8, "num_bits must be 4 or 8, got ", num_bits);
+  const bool w8 = num_bits == 8;
   // is_k_full = false is Marlin's mode for a row-parallel act-order shard: rows of one K shard belong
   // to groups all over the FULL scale table, looked up through g_idx.  This function takes the
   // packed weights at their checkpoint size, where that cannot be expressed; the layer classes
@@ -331,16 +354,22 @@ void gptq_gemm(const torch::Tensor& A, const torch::Tensor& B, torch::Tensor& C,
                 "act-order shard) is handled by slm::RowParallelQLinearHipImpl, not by the raw kernel entry point");
   TORCH_CHECK(A.dim() == 2 && C.dim() == 2 && A.stride(1) == 1 && C.stride(1) == 1);
   const int64_t M = A.size(0), K = A.size(1), N = C.size(1);
-  TORCH_CHECK(C.size(0) == M && B.numel() == K * N / 8 && B.scalar_type() == torch::kInt && B.is_contiguous(),
-              "B must be the int32 [K/16, N*16/8] tensor gptq_repack / awq_repack produced");
+  TORCH_CHECK(C.size(0) == M && B.numel() == K * N / (32 / num_bits) && B.scalar_type() == torch::kInt &&
+                  B.is_contiguous(),
+              "B must be the int32 [K/16, N*16/pack_factor] tensor gptq_repack / awq_repack produced");
   TORCH_CHECK(scales.dim() == 2 && scales.size(1) == N && scales.is_contiguous() &&
               scales.scalar_type() == A.scalar_type() && K % scales.size(0) == 0,
               "scales must be [n_groups, N] of the activation dtype, plain column order");
   const int64_t G = scales.size(0), gs = K / G;
   const bool zp = has_zp && zeros.defined() && zeros.numel() > 0;
   if (zp)
-    TORCH_CHECK(zeros.scalar_type() == torch::kInt && zeros.is_contiguous() && zeros.numel() == G * N / 8,
-                "zeros must be the AWQ checkpoint tensor [n_groups, N/8] int32");
+    TORCH_CHECK(zeros.scalar_type() == torch::kInt && zeros.is_contiguous() &&
+                    zeros.numel() == G * N / (32 / num_bits),
+                "zeros must be the AWQ checkpoint tensor [n_groups, N/pack_factor] int32");
+  // 8 bits: two int4 planes over 2K packed rows; the scale table is written at the packed group size
+  const int64_t Kp = w8 ? slm_w8_packed_rows(K) : K;
+  const int64_t gsp = w8 ? slm_w8_packed_group_size(K, gs) : gs;
+  TORCH_CHECK(gsp > 0, "unsupported group size ", gs, " for ", num_bits, "-bit weights");
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(A.device());
   torch::Tensor sz;
   {
@@ -348,7 +377,7 @@ void gptq_gemm(const torch::Tensor& A, const torch::Tensor& B, torch::Tensor& C,
     // modified in place by autograd-visible ops): those count as version 0
     const auto ver = [](const torch::Tensor& t) -> int64_t { return t.is_inference() ? 0 : static_cast<int64_t>(t._version()); };
     const SzKey key{scales.const_data_ptr(), zp ? zeros.const_data_ptr() : nullptr,
-                    ver(scales) * 65537 + (zp ? ver(zeros) : 0), K, N};
+                    ver(scales) * 65537 + (zp ? ver(zeros) : 0), w8 ? -K : K, N};
     std::lock_guard<std::mutex> lk(g_sz_mu);
     auto it = g_sz_cache.find(key);
     if (it != g_sz_cache.end() &&
@@ -361,11 +390,17 @@ void gptq_gemm(const torch::Tensor& A, const torch::Tensor& B, torch::Tensor& C,
       // (a model reload puts the layers at new addresses; their tables would otherwise live forever)
       for (auto e = g_sz_cache.begin(); e != g_sz_cache.end();)
         e = (e->second.scales_st.expired() || e->second.zeros_st.expired()) ? g_sz_cache.erase(e) : std::next(e);
-      sz = torch::empty({G * N}, torch::dtype(torch::kInt).device(A.device()));
-      check(slm_w4_prepack_sz(zp ? SLM_W4_AWQ : SLM_W4_GPTQ, zp ? zeros.const_data_ptr<int32_t>() : nullptr,
-                              scales.const_data_ptr(), K, N, gs, dtype_code(scales), sz.mutable_data_ptr(),
-                              current_stream(A)),
-            "slm_w4_prepack_sz");
+      sz = torch::empty({(Kp / gsp) * N}, torch::dtype(torch::kInt).device(A.device()));
+      if (w8)
+        check(slm_w8_prepack_sz(zp ? SLM_W8_AWQ : SLM_W8_GPTQ, zp ? zeros.const_data_ptr<int32_t>() : nullptr,
+                                scales.const_data_ptr(), K, N, gs, dtype_code(scales), sz.mutable_data_ptr(),
+                                current_stream(A)),
+              "slm_w8_prepack_sz");
+      else
+        check(slm_w4_prepack_sz(zp ? SLM_W4_AWQ : SLM_W4_GPTQ, zp ? zeros.const_data_ptr<int32_t>() : nullptr,
+                                scales.const_data_ptr(), K, N, gs, dtype_code(scales), sz.mutable_data_ptr(),
+                                current_stream(A)),
+              "slm_w4_prepack_sz");
       using WeakStorage = c10::weak_intrusive_ptr<c10::StorageImpl>;
       const auto& keep_alive_of_zeros = zp ? zeros : scales;
       g_sz_cache.emplace(key, SzEntry{sz, WeakStorage(scales.storage().getWeakStorageImpl()),
@@ -375,15 +410,21 @@ void gptq_gemm(const torch::Tensor& A, const torch::Tensor& B, torch::Tensor& C,
     }
   }
   const bool has_perm = perm.defined() && perm.numel() > 0;
+  torch::Tensor perm2;  // 8 bits: packed row k' reads activation column perm[k' mod K]
+  if (w8) {
+    const auto base = has_perm ? perm.to(torch::kInt)
+                               : torch::arange(K, torch::dtype(torch::kInt).device(A.device()));
+    perm2 = torch::cat({base, base}).contiguous();
+  }
   slm_w4_gemm_args g{};
   g.a = A.const_data_ptr();
   g.wq = B.const_data_ptr();
   g.sz = sz.const_data_ptr();
-  g.perm = has_perm ? perm.const_data_ptr<int32_t>() : nullptr;
+  g.perm = w8 ? perm2.const_data_ptr<int32_t>() : (has_perm ? perm.const_data_ptr<int32_t>() : nullptr);
   g.c = C.mutable_data_ptr();
-  g.M = M; g.K = K; g.N = N;
+  g.M = M; g.K = Kp; g.N = N;
   g.lda = A.stride(0); g.ldc = C.stride(0);
-  g.group_size = gs;
+  g.group_size = gsp;
   g.dtype = dtype_code(A);
   if (M == 0) return;
   const size_t need = slm_w4a16_gemm_workspace_bytes(&g);
@@ -407,12 +448,14 @@ size_t marlin_sz_cache_entries() {
 
 W4Linear::W4Linear(const std::string& quant_method, const torch::Tensor& qweight,
                    const torch::Tensor& qzeros, const torch::Tensor& scales,
-                   const std::optional<torch::Tensor>& g_idx, int64_t group_size) {
+                   const std::optional<torch::Tensor>& g_idx, int64_t group_size, int64_t bits) {
   const bool awq = quant_method == "awq";
   TORCH_CHECK(awq || quant_method == "gptq", "quant_method must be awq or gptq");
+  TORCH_CHECK(bits == 4 || bits == 8, "bits must be 4 or 8, got ", bits);
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(qweight.device());
-  K_ = awq ? qweight.size(0) : qweight.size(0) * 8;
-  N_ = awq ? qweight.size(1) * 8 : qweight.size(1);
+  const int64_t per = 32 / bits;
+  K_ = awq ? qweight.size(0) : qweight.size(0) * per;
+  N_ = awq ? qweight.size(1) * per : qweight.size(1);
   group_size_ = group_size > 0 ? group_size : K_;
   dtype_ = scales.scalar_type();
   if (!awq && g_idx.has_value() && g_idx->numel() > 0) {
@@ -426,6 +469,7 @@ W4Linear::W4Linear(const std::string& quant_method, const torch::Tensor& qweight
         // uneven groups after sorting: a row-parallel shard of an act-order checkpoint (sharded
         // qweight / g_idx, FULL scales: qlinear_gptq_marlin_impl.cpp:236-243,270-276; the reference
         // then runs Marlin with is_k_full = false, :319)
+        TORCH_CHECK(bits == 4, "act-order shards with uneven groups are supported for 4-bit weights only");
         pack_uneven_groups(qweight, qzeros, scales, gi, perm);
         return;
       }
@@ -433,6 +477,33 @@ W4Linear::W4Linear(const std::string& quant_method, const torch::Tensor& qweight
     }
   }
   k_src_ = K_;
+  if (bits == 8) {
+    // two int4 planes over 2K packed rows + the doubled activation gather (slm_hip.h section 3b)
+    const int64_t K = K_, gs = group_size_;
+    const int64_t gsp = slm_w8_packed_group_size(K, gs);
+    TORCH_CHECK(gsp > 0, "unsupported 8-bit group size ", gs);
+    K_ = slm_w8_packed_rows(K);
+    group_size_ = gsp;
+    const size_t wb = slm_w4_packed_weight_bytes(K_, N_), sb = slm_w4_packed_sz_bytes(K_, N_, gsp);
+    TORCH_CHECK(wb > 0 && sb > 0, "unsupported 8-bit shape K=", K, " N=", N_, " group=", gs);
+    const auto iopt = torch::dtype(torch::kInt).device(qweight.device());
+    wq_ = torch::empty({static_cast<int64_t>(wb / 4)}, iopt);
+    sz_ = torch::empty({static_cast<int64_t>(sb / 4)}, iopt);
+    auto perm2 = torch::empty({K_}, iopt);
+    const auto qw = qweight.contiguous(), sc = scales.contiguous();
+    const bool has_qz = qzeros.defined() && qzeros.numel() > 0;
+    const auto qz = has_qz ? qzeros.contiguous() : torch::Tensor();
+    const int fmt = awq ? SLM_W8_AWQ : SLM_W8_GPTQ;
+    check(slm_w8_prepack_weights(fmt, qw.const_data_ptr<int32_t>(),
+                                 perm_.defined() ? perm_.const_data_ptr<int32_t>() : nullptr, K, N_,
+                                 wq_.mutable_data_ptr(), perm2.mutable_data_ptr<int32_t>(), current_stream(qw)),
+          "slm_w8_prepack_weights");
+    check(slm_w8_prepack_sz(fmt, has_qz ? qz.const_data_ptr<int32_t>() : nullptr, sc.const_data_ptr(), K, N_, gs,
+                            dtype_code(sc), sz_.mutable_data_ptr(), current_stream(qw)),
+          "slm_w8_prepack_sz");
+    perm_ = perm2;
+    return;
+  }
   const size_t wb = slm_w4_packed_weight_bytes(K_, N_);
   const size_t sb = slm_w4_packed_sz_bytes(K_, N_, group_size_);
   TORCH_CHECK(wb > 0 && sb > 0, "unsupported int4 shape K=", K_, " N=", N_, " group=", group_size_);

@@ -84,7 +84,8 @@ void silu_and_mul(torch::Tensor& out, torch::Tensor input);
 //   perm     : [K] int32 act-order permutation (empty = none): gptq_repack sorts the weight rows
 //              by it, gptq_gemm gathers the activation columns by it (gptq_gemm.cu:69-118);
 //   workspace: ignored (no locks: split-K partials live in the library's own scratch);
-//   num_bits : 4 only; is_k_full / use_fp32_reduce: accepted, the reduction is always fp32.
+//   num_bits : 4 or 8 (8 = two int4 planes, include/slm_hip.h section 3b); is_k_full /
+//              use_fp32_reduce: accepted, the reduction is always fp32.
 namespace marlin {
 
 void gptq_gemm(const torch::Tensor& A,  // (m, k)
@@ -117,9 +118,11 @@ class W4Linear {
  public:
   // quant_method "awq": qweight [K, N/8], qzeros [G, N/8] (AWQ interleave), scales [G, N]
   // quant_method "gptq": qweight [K/8, N], qzeros [G, N/8], scales [G, N], optional g_idx [K]
+  // bits = 8: 4 values per int32 instead of 8 (byte order [0,2,1,3] for AWQ); packed as two int4
+  // planes over 2K rows (include/slm_hip.h section 3b), same forward()
   W4Linear(const std::string& quant_method, const torch::Tensor& qweight,
            const torch::Tensor& qzeros, const torch::Tensor& scales,
-           const std::optional<torch::Tensor>& g_idx, int64_t group_size);
+           const std::optional<torch::Tensor>& g_idx, int64_t group_size, int64_t bits = 4);
 
   // C[M, N] = A[M, K] . dequant(W) (+ bias); `out` may be pre-allocated
   torch::Tensor forward(const torch::Tensor& input, const std::optional<torch::Tensor>& bias,

@@ -155,8 +155,8 @@ class QuantArgs:
 class _QLinearBase:
     def __init__(self, in_features: int, out_features: int, bias: bool, quant_args: QuantArgs,
                  parallel_args: ParallelArgs, dtype: torch.dtype, device):
-        if quant_args.bits != 4:
-            raise kernels.SlmError("only 4-bit weights are supported (int8 Marlin path: out of scope)")
+        if quant_args.bits not in (4, 8):  # qlinear_awq_marlin_impl.cpp:25-26: 4 and 8
+            raise kernels.SlmError(f"only 4- and 8-bit weights are supported, got bits = {quant_args.bits}")
         self.in_features, self.out_features = in_features, out_features
         self.quant_args, self.parallel_args = quant_args, parallel_args
         self.dtype, self.device = dtype, device
@@ -183,11 +183,12 @@ class _QLinearBase:
         scales = c["scales"].to(self.dtype).contiguous()
         if self.quant_args.quant_method == "awq":
             self._packed = kernels.awq_repack(c["qweight"], c["qzeros"], scales,
-                                              self.quant_args.group_size, paired=self.paired)
+                                              self.quant_args.group_size, paired=self.paired,
+                                              bits=self.quant_args.bits)
         else:
             self._packed = kernels.gptq_repack(c["qweight"], c["qzeros"], scales,
                                                self.quant_args.group_size, c.get("g_idx"),
-                                               paired=self.paired)
+                                               paired=self.paired, bits=self.quant_args.bits)
         if self.has_bias:
             self.bias = c["bias"].to(self.dtype).contiguous()
             if self.paired:  # the bias follows the packed column order: gate / up 32-column tiles alternate

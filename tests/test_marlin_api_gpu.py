@@ -13,7 +13,9 @@ layout (the Marlin byte order is an NVIDIA mma.m16n8k16 artefact):
   * the repack tests cannot compare against the python Marlin packer; they check the repack
     BIT-EXACTLY through the GEMM instead: with A = identity and scales = 1 the GEMM returns
     (q - 8) for every weight, integers that fp16 holds exactly.
-num_bits = 8 (the reference's int8 Marlin path) is outside this hot path and must be refused.
+num_bits = 8 runs as two int4 planes (include/slm_hip.h section 3b): the full 4-bit grid plus the
+reference's m x n x k x group x act_order axes at 8 bits (is_k_full / use_fp32_reduce do not select
+different code here, so they are not multiplied into the 8-bit grid).
 quantize_weights / sort_rows are torch ports of tests/kernels/quant_utils.py:22-98.
 """
 import importlib.util
@@ -71,14 +73,16 @@ def sort_rows(q_w, g_idx):
     return q_w[perm.long()].contiguous(), g_idx[perm.long()].contiguous(), perm
 
 
-def pack_gptq_weights(q_w):
+def pack_gptq_weights(q_w, num_bits=4):
     import numpy as np
-    return torch.from_numpy(helpers.pack_rows(q_w.cpu().numpy().astype(np.int32))).to(q_w.device)
+    f = helpers.pack_rows if num_bits == 4 else helpers.pack_rows8
+    return torch.from_numpy(f(q_w.cpu().numpy().astype(np.int32))).to(q_w.device)
 
 
-def pack_awq_weights(q_w):
+def pack_awq_weights(q_w, num_bits=4):
     import numpy as np
-    return torch.from_numpy(helpers.pack_awq(q_w.cpu().numpy().astype(np.int32))).to(q_w.device)
+    f = helpers.pack_awq if num_bits == 4 else helpers.pack_awq8
+    return torch.from_numpy(f(q_w.cpu().numpy().astype(np.int32))).to(q_w.device)
 
 
 @pytest.mark.parametrize("m", [16, 32, 64])
@@ -90,9 +94,22 @@ def pack_awq_weights(q_w):
 @pytest.mark.parametrize("is_k_full", [False, True])
 @pytest.mark.parametrize("use_fp32_reduce", [False, True])
 def test_marlin_gemm(kernels, m, n, k, num_bits, group_size, act_order, is_k_full, use_fp32_reduce):
-    # the reference's grid (marlin_gemm_test.py:47-56) has num_bits {4, 8}: the 8-bit half is ONE
-    # refusal test below, not 768 parametrisations of it.  is_k_full = False on these full-K layers
-    # is the same computation as True (every group is whole): the shim checks that from g_idx.
+    # the reference's grid (marlin_gemm_test.py:47-56) has num_bits {4, 8}: the 8-bit half is
+    # test_marlin_gemm_8bit below.  is_k_full = False on these full-K layers is the same computation
+    # as True (every group is whole): the shim checks that from g_idx.
+    _marlin_gemm_case(kernels, m, n, k, num_bits, group_size, act_order, is_k_full, use_fp32_reduce)
+
+
+@pytest.mark.parametrize("m", [16, 32, 64])
+@pytest.mark.parametrize("n", [64, 128, 256, 512])
+@pytest.mark.parametrize("k", [128, 256])
+@pytest.mark.parametrize("group_size", [-1, 32, 64, 128])
+@pytest.mark.parametrize("act_order", [False, True])
+def test_marlin_gemm_8bit(kernels, m, n, k, group_size, act_order):
+    _marlin_gemm_case(kernels, m, n, k, 8, group_size, act_order, True, True)
+
+
+def _marlin_gemm_case(kernels, m, n, k, num_bits, group_size, act_order, is_k_full, use_fp32_reduce):
     if act_order and (group_size == -1 or group_size == k):
         pytest.skip("act_order=True requires group_size < k (marlin_gemm_test.py:64)")
     gen = torch.Generator(device="cuda").manual_seed(m * 7 + n * 3 + k + group_size)
@@ -102,12 +119,12 @@ def test_marlin_gemm(kernels, m, n, k, num_bits, group_size, act_order, is_k_ful
                                                act_order=act_order,
                                                generator=torch.Generator().manual_seed(k + n))
     # checkpoint-format weights -> this library's layout (rows sorted by group when act_order)
-    gptq_q_w = pack_gptq_weights(q_w)
+    gptq_q_w = pack_gptq_weights(q_w, num_bits)
     if act_order:
         _, g_idx, perm = sort_rows(q_w, g_idx)
     else:
         perm = torch.empty(0, dtype=torch.int32, device="cuda")
-    marlin_q_w = torch.empty(k // 16, n * 16 // 8, dtype=torch.int32, device="cuda")
+    marlin_q_w = torch.empty(k // 16, n * 16 // (32 // num_bits), dtype=torch.int32, device="cuda")
     kernels.marlin_gptq_repack(q_weight=gptq_q_w, perm=perm, out=marlin_q_w, num_bits=num_bits)
     marlin_s = s                                           # plain order: no permute_marlin_scales
     marlin_zp = torch.empty(0, dtype=torch.int32, device="cuda")
@@ -122,20 +139,23 @@ def test_marlin_gemm(kernels, m, n, k, num_bits, group_size, act_order, is_k_ful
     assert max_diff < 0.001
 
 
-def test_marlin_8bit_weights_are_refused(kernels):
-    """The int8 Marlin path (qlinear_awq_marlin_impl.cpp:25-26 accepts bits 4 and 8) is outside this
-    hot path (all BASELINE configs are int4): the entry points refuse it loudly."""
+def test_marlin_other_bit_widths_are_refused(kernels):
+    """The quantised linears take bits 4 and 8 (qlinear_awq_marlin_impl.cpp:25-26); anything else is
+    refused loudly by every entry point."""
     k, n = 128, 64
-    out = torch.empty(k // 16, n * 16 // 4, dtype=torch.int32, device="cuda")
+    out = torch.empty(k // 16, n * 16 // 16, dtype=torch.int32, device="cuda")
     empty = torch.empty(0, dtype=torch.int32, device="cuda")
-    with pytest.raises(RuntimeError, match="4-bit"):
-        kernels.marlin_gptq_repack(q_weight=torch.zeros(k // 4, n, dtype=torch.int32, device="cuda"),
-                                   perm=empty, out=out, num_bits=8)
-    with pytest.raises(RuntimeError, match="4-bit"):
+    with pytest.raises(RuntimeError, match="num_bits must be 4 or 8"):
+        kernels.marlin_gptq_repack(q_weight=torch.zeros(k // 16, n, dtype=torch.int32, device="cuda"),
+                                   perm=empty, out=out, num_bits=2)
+    with pytest.raises(RuntimeError, match="num_bits must be 4 or 8"):
+        kernels.marlin_awq_repack(q_weight=torch.zeros(k, n // 16, dtype=torch.int32, device="cuda"), out=out,
+                                  num_bits=2)
+    with pytest.raises(RuntimeError, match="num_bits must be 4 or 8"):
         kernels.marlin_gemm(A=torch.zeros(16, k, dtype=torch.half, device="cuda"), B=out,
                             C=torch.empty(16, n, dtype=torch.half, device="cuda"),
                             scales=torch.ones(1, n, dtype=torch.half, device="cuda"), zeros=empty, g_idx=empty,
-                            perm=empty, workspace=empty, num_bits=8, is_k_full=True, has_zp=False,
+                            perm=empty, workspace=empty, num_bits=2, is_k_full=True, has_zp=False,
                             use_fp32_reduce=True)
 
 
@@ -168,14 +188,15 @@ def test_marlin_gemm_refuses_an_uneven_act_order_shard_and_sweeps_its_table_cach
     assert kernels.marlin_sz_cache_entries() <= before + 2
 
 
-def _dequant_through_gemm(kernels, packed, k, n, perm):
-    """(q - 8) for every weight, exactly: GEMM with A = identity, scales = 1, symmetric zero."""
+def _dequant_through_gemm(kernels, packed, k, n, perm, num_bits=4):
+    """(q - 2^(bits-1)) for every weight, exactly: GEMM with A = identity, scales = 1, symmetric zero
+    (8 bits: 16 (hi - 8) + lo, integers <= 127 in magnitude that fp16 holds and sums exactly)."""
     eye = torch.eye(k, dtype=torch.half, device="cuda")
     ones = torch.ones(1, n, dtype=torch.half, device="cuda")
     out = torch.empty(k, n, dtype=torch.half, device="cuda")
     empty = torch.empty(0, dtype=torch.int32, device="cuda")
     kernels.marlin_gemm(A=eye, B=packed, C=out, scales=ones, zeros=empty, g_idx=empty, perm=perm,
-                        workspace=empty, num_bits=4, is_k_full=True, has_zp=False, use_fp32_reduce=True)
+                        workspace=empty, num_bits=num_bits, is_k_full=True, has_zp=False, use_fp32_reduce=True)
     torch.cuda.synchronize()
     return out
 
@@ -184,36 +205,38 @@ def _dequant_through_gemm(kernels, packed, k, n, perm):
 @pytest.mark.parametrize("n", [64, 128, 256])
 @pytest.mark.parametrize("group_size", [-1, 32, 64, 128])
 @pytest.mark.parametrize("act_order", [False, True])
-def test_gptq_repack(kernels, k, n, group_size, act_order):
+@pytest.mark.parametrize("num_bits", [4, 8])
+def test_gptq_repack(kernels, k, n, group_size, act_order, num_bits):
     if act_order and group_size in (-1, k):
         return
     w = torch.randn((k, n), dtype=torch.half, device="cuda")
-    _, q_w, _, g_idx, _ = quantize_weights(w, num_bits=4, group_size=group_size, act_order=act_order,
+    _, q_w, _, g_idx, _ = quantize_weights(w, num_bits=num_bits, group_size=group_size, act_order=act_order,
                                            generator=torch.Generator().manual_seed(n))
-    gptq_q_w = pack_gptq_weights(q_w)
+    gptq_q_w = pack_gptq_weights(q_w, num_bits)
     if act_order:
         _, g_idx, perm = sort_rows(q_w, g_idx)
     else:
         perm = torch.empty(0, dtype=torch.int32, device="cuda")
-    out = torch.empty(k // 16, n * 16 // 8, dtype=torch.int32, device="cuda")
-    kernels.marlin_gptq_repack(q_weight=gptq_q_w, perm=perm, out=out, num_bits=4)
+    out = torch.empty(k // 16, n * 16 // (32 // num_bits), dtype=torch.int32, device="cuda")
+    kernels.marlin_gptq_repack(q_weight=gptq_q_w, perm=perm, out=out, num_bits=num_bits)
     # identity x W in CHECKPOINT row order (the GEMM gathers A's columns by perm, so row i of the
     # result is checkpoint row i again)
-    got = _dequant_through_gemm(kernels, out, k, n, perm)
-    assert torch.equal(got, (q_w - 8).to(torch.half))
+    got = _dequant_through_gemm(kernels, out, k, n, perm, num_bits)
+    assert torch.equal(got, (q_w - 2 ** (num_bits - 1)).to(torch.half))
 
 
 @pytest.mark.parametrize("k", [128, 256])
 @pytest.mark.parametrize("n", [64, 128, 256])
 @pytest.mark.parametrize("group_size", [-1, 32, 64, 128])
-def test_awq_repack(kernels, k, n, group_size):
+@pytest.mark.parametrize("num_bits", [4, 8])
+def test_awq_repack(kernels, k, n, group_size, num_bits):
     w = torch.randn((k, n), dtype=torch.half, device="cuda")
-    _, q_w, _, _, _ = quantize_weights(w, num_bits=4, group_size=group_size)
-    awq_q_w = pack_awq_weights(q_w)
-    out = torch.empty(k // 16, n * 16 // 8, dtype=torch.int32, device="cuda")
-    kernels.marlin_awq_repack(q_weight=awq_q_w, out=out, num_bits=4)
-    got = _dequant_through_gemm(kernels, out, k, n, torch.empty(0, dtype=torch.int32, device="cuda"))
-    assert torch.equal(got, (q_w - 8).to(torch.half))
+    _, q_w, _, _, _ = quantize_weights(w, num_bits=num_bits, group_size=group_size)
+    awq_q_w = pack_awq_weights(q_w, num_bits)
+    out = torch.empty(k // 16, n * 16 // (32 // num_bits), dtype=torch.int32, device="cuda")
+    kernels.marlin_awq_repack(q_weight=awq_q_w, out=out, num_bits=num_bits)
+    got = _dequant_through_gemm(kernels, out, k, n, torch.empty(0, dtype=torch.int32, device="cuda"), num_bits)
+    assert torch.equal(got, (q_w - 2 ** (num_bits - 1)).to(torch.half))
 
 
 def test_marlin_gemm_with_zero_points_awq_checkpoint(kernels):

@@ -238,6 +238,43 @@ def test_cpp_row_parallel_act_order_gptq_shards(shim, world):
     assert rel(total) < 8e-3 * (1 + 0.5 * np.sqrt(world))
 
 
+@pytest.mark.parametrize("fmt", ["awq", "gptq"])
+def test_cpp_parallel_qlinear_impls_8bit(shim, fmt):
+    """bits = 8 (qlinear_awq_marlin_impl.cpp:25-26 accepts 4 and 8) through the C++ layers: the shards
+    of the 8-bit checkpoint tensors (4 values per int32) are packed as two int4 planes at the first
+    forward; world 1 == oracle (construct_weights with bits = 8), TP = 2 column / row shards agree."""
+    K, N, gs, M = 512, 256, 128, 24
+    case = helpers.make_quant8_case(61, K, N, gs, fmt, "bf16")
+    sd = _ckpt(case)
+    args = (fmt, 8, gs, False, False, fmt == "awq")   # bits, group, desc_act, is_sym, zero_point
+    a = torch.randn(M, K, device=DEV, dtype=torch.bfloat16)
+    ref = oracle.gemm_f32(a.float().cpu().numpy(), helpers.dense_weight8(case))
+    rel = lambda got: float(np.abs(got.float().cpu().numpy() - ref).mean() / np.abs(ref).mean())  # noqa: E731
+    col = shim.create_column_parallel_qlinear(K, N, False, False, *args, 0, 1, torch.bfloat16, 0)
+    col.load_state_dict(sd)
+    col.verify_loaded_weights("layer.0.")
+    assert rel(col.forward(a)) < 8e-3
+    cols = []
+    for r in range(2):
+        lin = shim.create_column_parallel_qlinear(K, N, False, False, *args, r, 2, torch.bfloat16, 0)
+        lin.load_state_dict(sd)
+        cols.append(lin.forward(a))
+    assert cols[0].shape == (M, N // 2) and rel(torch.cat(cols, dim=-1)) < 8e-3
+    parts = []
+    for r in range(2):
+        lin = shim.create_row_parallel_qlinear(K, N, False, False, *args, r, 2, torch.bfloat16, 0)
+        lin.load_state_dict(sd)
+        parts.append(lin.forward(a).float())
+    assert rel((parts[0] + parts[1]).to(torch.bfloat16)) < 8e-3
+    # and the Python mirror of the same layer gives the same bits as the C++ one at world 1
+    from scalellm_amd import layers
+    from scalellm_amd.model_parallel import ParallelArgs
+    py = layers.ColumnParallelQLinear(K, N, False, layers.QuantArgs(fmt, 8, gs, False, fmt == "awq"), False,
+                                      ParallelArgs(0, 1, None), torch.bfloat16, DEV)
+    py.load_state_dict({k: v.to(DEV) for k, v in sd.items()})
+    assert torch.equal(py.forward(a), col.forward(a))
+
+
 def test_cpp_parallel_qlinear_fused_load_and_argument_checks(shim):
     """The fused (qkv / gate_up) load path: one checkpoint tensor set per prefix, arriving in any
     order and possibly in different state-dict files, concatenated on dim 1; and the reference's
@@ -265,8 +302,8 @@ def test_cpp_parallel_qlinear_fused_load_and_argument_checks(shim):
         mk(K, 256, False, False, "awq", 4, gs, False, True, False, 0, 1, torch.bfloat16, 0)
     with pytest.raises(RuntimeError, match="group_size"):
         mk(K, 256, False, False, "awq", 4, 48, False, False, True, 0, 1, torch.bfloat16, 0)
-    with pytest.raises(RuntimeError, match="4-bit"):
-        mk(K, 256, False, False, "gptq", 8, gs, False, True, False, 0, 1, torch.bfloat16, 0)
+    with pytest.raises(RuntimeError, match="4 and 8 bits"):
+        mk(K, 256, False, False, "gptq", 2, gs, False, True, False, 0, 1, torch.bfloat16, 0)
     with pytest.raises(RuntimeError, match="not divisible"):
         mk(K, 250, False, False, "awq", 4, gs, False, False, True, 0, 4, torch.bfloat16, 0)
 
