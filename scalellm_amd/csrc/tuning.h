@@ -22,7 +22,6 @@ enum TuneKey : int {
   TUNE_ATTN_TILE_DECODE,  // SLM_ATTN_TILE_DECODE  min GQA group at which q_len = 1 goes to the tile kernel (default 8, 0 = never)
   TUNE_ATTN_BAL,          // SLM_ATTN_BAL          0 = classic per-sequence split-KV for pure decode (no balanced partition)
   TUNE_W4_GEMV,           // SLM_W4_GEMV           0 off, 1 = M == 1 only, 2 = M <= 4
-  TUNE_W4_GEMV_REFILL,    // SLM_W4_GEMV_REFILL
   TUNE_W4_GEMV_KS,        // SLM_W4_GEMV_KS        forced K slices per GEMV workgroup (1/2/4/8)
   TUNE_W4_SMALL,          // SLM_W4_SMALL          0 = never use the small-M kernel
   TUNE_W4_MT,             // SLM_W4_MT             forced M tile (1/2/4/8/16)

@@ -500,6 +500,14 @@ __global__ void __launch_bounds__(256) w4_splitk_reduce_silu_kernel(
 }
 
 // ------------------------------- host side ------------------------------------------
+// Instantiations of the general kernel that do not fit 256 VGPRs (hipcc spills: measured 4-7x
+// SLOWER than the PRE form of the same tile -- group 32 at 32 < M <= 64, qkv 83 vs 19 us) are neither
+// planned nor built: the post-scaled form needs one more accumulator set per scale group and tile.
+constexpr bool w4_post_fits(int mt, int ntw, int ng, int pc) {
+  return mt <= 2 && ntw == 1 && !(ng == 4 && (mt == 2 || pc >= 2));
+}
+constexpr bool w4_pre_fits(int /*mt*/, int ntw, int ng, int pc) { return !(ntw == 2 && ng == 4 && pc >= 2); }
+
 struct GemmPlan {
   int mt, ntw, ng, pc, post, small, gemv, split_k, chunks_per_split, n_mblocks, n_nblocks;
   int ks, ks_cw, ks_nw, ks_tpw;  // K-sliced small-M kernel (w4_ks.hip)
@@ -579,6 +587,7 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   if (pc != 1 && pc != 2 && pc != 4) pc = 1;
   if (pc * mt > 4) pc = mt >= 4 ? 1 : 4 / mt;
   while (pc > 1 && n_chunks % pc) pc >>= 1;
+  if (!w4_pre_fits(mt, ntw, pl->ng, pc)) pc = 1;  // (a knob combination that does not fit the registers)
   const int n_units = n_chunks / pc;  // split-K granularity = whole passes
   int split_k = tune_get(TUNE_W4_SPLITK, 0);
   if (split_k <= 0) {
@@ -599,7 +608,7 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   pl->chunks_per_split = units_per_split * pc;
   pl->split_k = (n_units + units_per_split - 1) / units_per_split;
   // small-M tiles use the post-scaled form (7 VALU per 8 weights instead of ~27)
-  pl->post = tune_get(TUNE_W4_POST, a->M <= 64 ? 1 : 0) != 0 && mt <= 2;
+  pl->post = tune_get(TUNE_W4_POST, a->M <= 64 ? 1 : 0) != 0 && w4_post_fits(mt, ntw, pl->ng, pc);
   pl->lds_bytes = (size_t)2 * pc * bm * 256 + (pl->post ? (size_t)2 * pc * pl->ng * bm * sizeof(float) : 0);
   if (pl->gemv) {
     // K is split inside the workgroup: no partials, no reduce launch.  Exception: when the caller
@@ -668,18 +677,16 @@ static void launch_gemm_ng(const GemmKParams& kp, const GemmPlan& pl, hipStream_
   const dim3 grid((unsigned)((int64_t)pl.n_nblocks * pl.n_mblocks * pl.split_k)), blk(256);
 #define SLM_GEMM(NGG, POSTT)                                                                        \
   hipLaunchKernelGGL((w4a16_gemm_kernel<T, MT, NTW, NGG, PC, POSTT>), grid, blk, pl.lds_bytes, st, kp)
-  if constexpr (MT <= 2) {
-    if (pl.post) {
-      switch (pl.ng) {
-        case 4: SLM_GEMM(4, true); break;
-        case 2: SLM_GEMM(2, true); break;
-        default: SLM_GEMM(1, true); break;
-      }
-      return;
+  if (pl.post) {  // (plan_gemm only sets it where w4_post_fits: the other instantiations are not built)
+    switch (pl.ng) {
+      case 4: if constexpr (w4_post_fits(MT, NTW, 4, PC)) SLM_GEMM(4, true); break;
+      case 2: if constexpr (w4_post_fits(MT, NTW, 2, PC)) SLM_GEMM(2, true); break;
+      default: if constexpr (w4_post_fits(MT, NTW, 1, PC)) SLM_GEMM(1, true); break;
     }
+    return;
   }
   switch (pl.ng) {
-    case 4: SLM_GEMM(4, false); break;
+    case 4: if constexpr (w4_pre_fits(MT, NTW, 4, PC)) SLM_GEMM(4, false); break;
     case 2: SLM_GEMM(2, false); break;
     default: SLM_GEMM(1, false); break;
   }

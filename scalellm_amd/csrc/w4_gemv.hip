@@ -352,18 +352,15 @@ __global__ void __launch_bounds__(512) w4a16_gemv_kernel(const GemvParams p) {
 
 template <typename T, int NGC>
 static void launch_gemv_m(const GemvParams& gp, int n_wgs, size_t lds, hipStream_t st) {
-  // measured: keeping the (clamped, L2-hit) refills even when the slice fits the ring is FASTER on
-  // the wide layers (gate_up M=1 17.5-19 us vs 23.4 us without them) -- the extra loads keep the
-  // issue pattern the compiler's counted waits were built for; SLM_W4_GEMV_REFILL=0 disables them
-  const bool refill = (gp.n64 + gp.ks * gp.splits - 1) / (gp.ks * gp.splits) > GV_RING ||
-                      tune_get(TUNE_W4_GEMV_REFILL, 1) != 0;
+  // The ring is always refilled (REFILL = true), even when the wave's K slice fits it: measured, the
+  // clamped (L2-hit) extra loads are FASTER on the wide layers (gate_up M=1 17.5-19 us vs 23.4 us
+  // without them) -- they keep the issue pattern the compiler's counted waits were built for.  The
+  // no-refill instantiations were only reachable through a tuning knob and were the ones at the
+  // 256-VGPR cap with spills; they are no longer built.
 #define SLM_GEMV(MTT)                                                                          \
   do {                                                                                         \
-    auto kfn = gp.norm_weight                                                                  \
-                   ? (refill ? w4a16_gemv_kernel<T, NGC, MTT, true, true>                      \
-                             : w4a16_gemv_kernel<T, NGC, MTT, false, true>)                    \
-                   : (refill ? w4a16_gemv_kernel<T, NGC, MTT, true, false>                     \
-                             : w4a16_gemv_kernel<T, NGC, MTT, false, false>);                  \
+    auto kfn = gp.norm_weight ? w4a16_gemv_kernel<T, NGC, MTT, true, true>                     \
+                              : w4a16_gemv_kernel<T, NGC, MTT, true, false>;                   \
     if (lds > 65536) {                                                                         \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);       \

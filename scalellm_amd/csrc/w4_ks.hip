@@ -546,8 +546,12 @@ static void launch_ks_t(const GemmKParams& kp, int n_blocks, hipStream_t st) {
 
 template <typename T, int CW, int NG>
 static void launch_ks_nw(const GemmKParams& kp, int nw, int n_blocks, hipStream_t st) {
-  if (nw == 4) launch_ks_t<T, CW, NG, 4>(kp, n_blocks, st);
-  else launch_ks_t<T, CW, NG, 8>(kp, n_blocks, st);
+  if (nw == 4) {
+    // (CW = 4, NG = 2, NW = 4) spills at the 256-VGPR cap: refused by gemm_ks_config_ok, not built
+    if constexpr (!(CW == 4 && NG == 2)) launch_ks_t<T, CW, NG, 4>(kp, n_blocks, st);
+  } else {
+    launch_ks_t<T, CW, NG, 8>(kp, n_blocks, st);
+  }
 }
 
 template <typename T, int CW>
