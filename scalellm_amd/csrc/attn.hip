@@ -690,9 +690,15 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
   // Measured (profiles/r03_attn_serving.jsonl, classic -> balanced): bs = 256 ragged 5.80 -> 6.43 TB/s,
   // uniform 6.91 -> 6.85 (the combine launch that only exits); bs = 32 ragged 5.07 -> 5.37, uniform
   // 5.73 -> 5.65; bs = 8 loses both ways (few sequences: the binary search and the piece
-  // bookkeeping are not amortised) -- hence the batch floor.  SLM_ATTN_BAL: 0 = never, 2 = always.
+  // bookkeeping are not amortised) -- hence the batch floor.  And only when a workgroup streams
+  // >= 4 KV heads of its tokens: with one KV head per workgroup (a TP = 8 shard of Llama-3: 4 q / 1 kv
+  // heads, 2 MiB per workgroup) the same bookkeeping is 5 % of the launch and a ragged batch
+  // gains nothing (bs = 256: uniform 86.5 -> 91.0 us, ragged 77.8 -> 77.5 us).
+  // SLM_ATTN_BAL: 0 = never, 2 = always.
   const int bal_mode = tune_get(TUNE_ATTN_BAL, 1);
-  if (bal_mode != 0 && (a->n_tokens >= 16 || bal_mode == 2) && a->max_q_len <= 1 && a->n_tokens == a->batch_size &&
+  const bool bal_pays = ((1 << pl->hpw_shift) << pl->hgw_shift) >= 4;
+  if (bal_mode != 0 && ((a->n_tokens >= 16 && bal_pays) || bal_mode == 2) && a->max_q_len <= 1 &&
+      a->n_tokens == a->batch_size &&
       a->sliding_window < 0 && forced_splits <= 0 && !decode_on_tile(a) && a->n_tokens > 0) {
     int slots = n_splits + 1 > 9 ? n_splits + 1 : 9;
     if (slots > COMBINE_MAX_SPLITS) slots = COMBINE_MAX_SPLITS;

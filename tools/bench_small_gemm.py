@@ -24,6 +24,8 @@ from scalellm_amd.decode import _rand_int4_linear  # noqa: E402
 SHAPES = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "down": (14336, 4096),
           # Llama-3-70B TP=8 rank shards (BASELINE configs[3])
           "qkv70": (8192, 10240), "o70": (8192, 8192), "gate_up70": (8192, 57344), "down70": (28672, 8192),
+          # Llama-3-8B TP=8 rank shards (what bench.py --gpus 8 runs per rank)
+          "qkv8tp8": (4096, 768), "o8tp8": (512, 4096), "gate_up8tp8": (4096, 3584), "down8tp8": (1792, 4096),
           "qkv70tp8": (8192, 1280), "o70tp8": (1024, 8192), "gate_up70tp8": (8192, 7168), "down70tp8": (3584, 8192)}
 
 
