@@ -195,6 +195,30 @@ def test_w4_host_side_planning_and_validation():
     assert L.slm_set_kv_cache(None, None, None, 0, 0, None, None, 3, 8, 128, 1, None) == -1
 
 
+def test_w8_plane_form_host_side():
+    """8-bit weights (slm_hip.h section 3b): sizes and argument validation are pure host code that
+    runs before any launch -- packed rows = 2K, the packed group size (the checkpoint's when the int4
+    GEMM supports it, else 128-row granularity), format / shape / pointer checks."""
+    L = _lib.lib()
+    assert L.slm_w8_packed_rows(4096) == 8192 and L.slm_w8_packed_rows(0) == 0
+    for K, gs, want in ((4096, 128, 128), (4096, 64, 64), (4096, 32, 32), (4096, 4096, 4096), (4096, 1024, 1024),
+                        (14336, 14336, 128),   # per-channel, K not a power of two: written out per 128 rows
+                        (384, 384, 128), (4096, 48, 0), (4096, 96, 0), (4096, 3000, 0), (0, 128, 0)):
+        assert L.slm_w8_packed_group_size(K, gs) == want, (K, gs)
+    W8G, W8A = _lib.SLM_W8_GPTQ, _lib.SLM_W8_AWQ
+    # slm_w8_prepack_weights(format, qweight, perm, K, N, wq_out, perm2_out, stream)
+    assert L.slm_w8_prepack_weights(W8G, None, None, 128, 64, 256, 512, None) == -1        # NULL qweight
+    assert L.slm_w8_prepack_weights(W8G, 256, None, 128, 64, 256, None, None) == -1        # NULL perm2_out
+    assert L.slm_w8_prepack_weights(_lib.SLM_W4_GPTQ, 256, None, 128, 64, 256, 512, None) == -2   # a 4-bit format
+    assert L.slm_w8_prepack_weights(W8A, 256, None, 100, 64, 256, 512, None) == -2         # K % 64
+    assert L.slm_w8_prepack_weights(W8A | _lib.SLM_W4_PAIRED, 256, None, 128, 96, 256, 512, None) == -2  # paired: N % 64
+    # slm_w8_prepack_sz(format, qzeros, scales, K, N, group_size, dtype, sz_out, stream)
+    assert L.slm_w8_prepack_sz(W8G, None, None, 128, 64, 128, 1, 256, None) == -1          # NULL scales
+    assert L.slm_w8_prepack_sz(W8G, None, 256, 128, 64, 48, 1, 256, None) == -2            # group size
+    assert L.slm_w8_prepack_sz(W8G, None, 256, 128, 64, 128, 7, 256, None) == -2           # dtype
+    assert L.slm_w8_prepack_sz(_lib.SLM_W4_AWQ, None, 256, 128, 64, 128, 1, 256, None) == -2
+
+
 def test_deferred_splitk_reduce_host_side():
     """SLM_W4_DEFER_REDUCE: whether a call defers is a pure function of its argument block, and
     slm_rms_norm_splitk validates before any launch."""

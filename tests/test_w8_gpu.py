@@ -144,6 +144,24 @@ def test_llama_layer_shapes_8bit_every_kernel_regime(M, K, N):
     assert _rel_err(c.float().cpu().numpy(), ref) < GEMM_TOL["bf16"]
 
 
+@pytest.mark.parametrize("K", [384, 1792])
+@pytest.mark.parametrize("fmt", ["gptq", "awq"])
+def test_per_channel_scales_with_k_not_a_power_of_two(K, fmt):
+    """group_size = -1 (one scale row for all of K) with K = 3 x 128 / 14 x 128: the int4 GEMM wants
+    power-of-two groups, so the packed table is written out at 128-row granularity
+    (slm_w8_packed_group_size) -- 2K / 128 identical-per-plane rows."""
+    from scalellm_amd import kernels
+    case = helpers.make_quant8_case(17 + K, K, 128, -1, fmt, "bf16", sym=(fmt == "gptq"))
+    packed = helpers.pack_case8(case, "bf16")
+    assert packed.group_size == 128 and packed.K == 2 * K and packed.sz.numel() == (2 * K // 128) * 128
+    for M in (3, 40, 200):
+        a = torch.randn(M, K, device=DEV, dtype=torch.bfloat16, generator=torch.Generator(device=DEV).manual_seed(M))
+        c = torch.empty(M, 128, device=DEV, dtype=torch.bfloat16)
+        kernels.gptq_gemm(a, packed, c)
+        ref = a.float().cpu().numpy() @ helpers.dense_weight8(case)
+        assert _rel_err(c.float().cpu().numpy(), ref) < GEMM_TOL["bf16"], (K, fmt, M)
+
+
 def test_8bit_paired_gate_up_fuses_silu_mul():
     """SLM_W4_PAIRED composes with the plane form: silu(gate) * up in the GEMM epilogue is
     bit-identical to the unfused GEMM + slm_silu_mul."""
