@@ -91,6 +91,24 @@ __global__ void __launch_bounds__(512) read_stream_kernel(const uint32_t* src, s
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = acc.x;
 }
 
+// the same stream, grid-strided: consecutive waves read consecutive KiB (wave w takes KiB w, w + W, ...)
+template <int DEPTH>
+__global__ void __launch_bounds__(512) read_stream_strided_kernel(const uint32_t* src, size_t total_kib, uint32_t* sink) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const size_t W = (size_t)gridDim.x * 8;
+  const size_t wave = (size_t)blockIdx.x * 8 + (threadIdx.x >> 6);
+  const u32x4* p = reinterpret_cast<const u32x4*>(src) + (threadIdx.x & 63);
+  u32x4 acc = {0u, 0u, 0u, 0u};
+  for (size_t i = wave; i + (DEPTH - 1) * W < total_kib; i += DEPTH * W) {
+    u32x4 v[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) v[d] = __builtin_nontemporal_load(p + (i + d * W) * 64);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) acc ^= v[d];
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = acc.x;
+}
+
 struct Stats {
   double mhz_med, mhz_min, mhz_max, window_us;
   int n;
@@ -203,6 +221,22 @@ int main() {
       snprintf(name, sizeof(name), "read-only stream 8 GiB, %d workgroups x 8 waves, 8 x 16 B in flight per lane", wgs);
       run_load(name, (double)bytes / 1e6, "tbps", [&](hipStream_t st) {
         hipLaunchKernelGGL(read_stream_kernel<8>, dim3(wgs), dim3(512), 0, st, src, words_per_wave, (uint32_t*)sink);
+      }, 1, 8);
+    }
+    for (int wgs : {256, 512, 2048}) {
+      char name[160];
+      snprintf(name, sizeof(name), "read-only stream 8 GiB, grid-strided (adjacent waves read adjacent KiB), %d workgroups, 8 in flight", wgs);
+      run_load(name, (double)bytes / 1e6, "tbps", [&](hipStream_t st) {
+        hipLaunchKernelGGL(read_stream_strided_kernel<8>, dim3(wgs), dim3(512), 0, st, src, bytes / 1024, (uint32_t*)sink);
+      }, 1, 8);
+    }
+    for (int wgs : {256, 512}) {
+      const size_t waves = (size_t)wgs * 8;
+      const size_t words_per_wave = bytes / 4 / waves;
+      char name[160];
+      snprintf(name, sizeof(name), "read-only stream 8 GiB, %d workgroups x 8 waves, 16 x 16 B in flight per lane", wgs);
+      run_load(name, (double)bytes / 1e6, "tbps", [&](hipStream_t st) {
+        hipLaunchKernelGGL(read_stream_kernel<16>, dim3(wgs), dim3(512), 0, st, src, words_per_wave, (uint32_t*)sink);
       }, 1, 8);
     }
     CK(hipFree(src));
