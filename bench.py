@@ -637,6 +637,11 @@ def main():
             "roofline": roofline,
             "int4_gemm": gemm,
             "cpu_baseline": cpu,
+            # context, NOT measured by this run: what a kernel that does nothing else reaches on an
+            # MI355X (tools/probes/clock_probe.hip; roofline.peak stays the datasheet figure)
+            "calibration": {"hbm_read_only_stream_GBps": 7000, "mfma_bf16_random_operands_tflops": 1690,
+                            "mfma_bf16_zero_operands_tflops": 2310,
+                            "source": "profiles/r03_clock_under_load.jsonl (separate probe run, same GPU model)"},
         }
         print(json.dumps(out), flush=True)
     if world > 1:
