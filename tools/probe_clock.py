@@ -106,6 +106,34 @@ def main():
     watch("decode attention bs 256 L 4096 (2 launches per replay)", gr, 8, dict(algorithmic_bytes_per_replay=nbytes), fout)
     del caches
 
+
+    # ---- MFMA tile attention: causal prefill 4 x 2048 and chunked prefill 8 x 256 over a 4 k history
+    for name, seqs, reps in (("attention prefill 4 x 2048 causal (tile kernel)", [(2048, 2048)] * 4, 12),
+                             ("attention chunked prefill 8 x 256 over 4096 (tile kernel)", [(256, 4096)] * 8, 12)):
+        q_lens, kv_lens = [a for a, _ in seqs], [b for _, b in seqs]
+        _, _, pp, nb = make_batch_inputs(q_lens, kv_lens, B, dev, seed=5)
+        T = sum(q_lens)
+        qq = torch.randn(T, H, D, device=dev, dtype=torch.bfloat16, generator=g)
+        kc = torch.randn(nb * B, HKV, D, device=dev, dtype=torch.bfloat16, generator=g)
+        vc = torch.randn(nb * B, HKV, D, device=dev, dtype=torch.bfloat16, generator=g)
+        oo = torch.empty_like(qq)
+
+        def pre():
+            kernels.paged_kv_varlen_mha(oo, qq, kc, vc, pp.q_cu_seq_lens, pp.kv_cu_seq_lens, pp.block_tables,
+                                        pp.cu_block_lens, None, B, max(q_lens), max(kv_lens), D ** -0.5)
+
+        pre()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(8):
+                pre()
+        gr.replay()
+        torch.cuda.synchronize()
+        vis = sum(ql * (kl - ql) + ql * (ql + 1) // 2 for ql, kl in seqs)
+        watch(name + " (8 launches per replay)", gr, reps, dict(flops_per_replay=8 * 4.0 * vis * H * D), fout)
+        del kc, vc
+
     # ---- int4 layer chains
     shapes = [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)]
     gen = torch.Generator(device=dev).manual_seed(3)
