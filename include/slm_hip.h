@@ -383,6 +383,31 @@ SLM_API int slm_decode_advance(int32_t* positions /* [n_seqs] */, int32_t* kv_cu
                                int32_t n_seqs, int32_t block_size, int32_t* overflow_flag /* [1], may be NULL */,
                                void* stream);
 
+/* The same for ANY batch (prefill chunks, speculative-verify rows and decode rows mixed, sequences
+ * joining or leaving between steps): the integer inputs of a step built on the device from two small
+ * per-sequence arrays and the persistent block table, instead of the per-token host loops and the
+ * H2D copy of the flattened table of Batch::prepare_model_input (engine/batch.cpp:97-255).
+ * For sequence b with n_kv = kv_cached[b] tokens already in the cache and q = max(q_lens[b], 0) new ones:
+ *     q_cu_lens[b+1]  = q_cu_lens[b]  + q                                   (batch.cpp:139-140)
+ *     kv_cu_lens[b+1] = kv_cu_lens[b] + n_kv + q
+ *     for j in [n_kv, n_kv + q), t = q_cu_lens[b] + (j - n_kv):
+ *         positions[t]       = j                                            (batch.cpp:155)
+ *         new_cache_slots[t] = block_table[block_cu_lens[b] + j / B] + j % B (sequence.cpp:303-317)
+ *     commit != 0: kv_cached[b] += q afterwards         (Sequence::commit_kv_cache, batch.cpp:197)
+ * Rows t in [q_cu_lens[n_seqs], n_tokens_padded) are the graph padding of batch.cpp:219-244:
+ * position 0, slot 0.  A position without a block sets *overflow_flag |= 1 and is clamped to the
+ * sequence's last block (the host then discards the step).  A sequence with q = 0 (no token budget
+ * this step: the reference drops it from the batch, batch.cpp:113-117) stays in the arrays as an
+ * empty row range; the attention kernels skip it.  The host keeps what only it can decide: which
+ * sequences run, their token budgets (q_lens), block allocation (appending first-slot ids).
+ * block_size must be a power of two.  Bit-exact integer contract; one launch, capture-safe. */
+SLM_API int slm_build_step_inputs(const int32_t* q_lens /* [n_seqs] */, int32_t* kv_cached /* [n_seqs] */,
+                                  const int32_t* block_table, const int32_t* block_cu_lens /* [n_seqs+1] */,
+                                  int32_t n_seqs, int32_t block_size, int32_t n_tokens_padded, int32_t commit,
+                                  int32_t* positions /* [n_tokens_padded] */, int32_t* q_cu_lens /* [n_seqs+1] */,
+                                  int32_t* kv_cu_lens /* [n_seqs+1] */, int32_t* new_cache_slots /* [n_tokens_padded] */,
+                                  int32_t* overflow_flag /* [1], may be NULL */, void* stream);
+
 /* ========================================================================== */
 /* 6. xGMI all-reduce fused with residual-add + RMSNorm    */
 /*    replaces  ProcessGroupNCCL::allreduce  (ncclAllReduce SUM, in place)    */

@@ -81,6 +81,24 @@ def decode_advance(positions, kv_cu_lens, block_table, block_cu_lens, block_size
     return pos, kcu, slots, int(missing)
 
 
+def build_step_inputs(q_lens, kv_cached, block_table, block_cu_lens, block_size: int, n_tokens_padded: int):
+    """(positions, q_cu_lens, kv_cu_lens, new_cache_slots, n_missing_blocks) of one step for any mix
+    of sequences (Batch::prepare_model_input, engine/batch.cpp:97-255)."""
+    ql, kc = _i32(q_lens), _i32(kv_cached)
+    bt, bcu = _i32(block_table), _i32(block_cu_lens)
+    n = len(ql)
+    pos = np.zeros(n_tokens_padded, np.int32)
+    slots = np.zeros(n_tokens_padded, np.int32)
+    qcu = np.zeros(n + 1, np.int32)
+    kcu = np.zeros(n + 1, np.int32)
+    fn = lib().oracle_build_step_inputs
+    fn.restype = C.c_int32
+    missing = fn(_p(ql, _i32p), _p(kc, _i32p), _p(bt, _i32p), _p(bcu, _i32p), C.c_int32(n),
+                 C.c_int32(block_size), C.c_int32(n_tokens_padded), _p(pos, _i32p), _p(qcu, _i32p),
+                 _p(kcu, _i32p), _p(slots, _i32p))
+    return pos, qcu, kcu, slots, int(missing)
+
+
 def set_kv_cache(slot_ids, keys: np.ndarray, values: np.ndarray, key_cache: np.ndarray,
                  value_cache: np.ndarray) -> None:
     """In-place scatter (any element type; rows are [n_kv_heads, head_dim])."""

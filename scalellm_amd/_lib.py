@@ -107,6 +107,10 @@ def lib() -> C.CDLL:
     L.slm_paged_kv_varlen_mha_auto_splits.argtypes = [C.POINTER(AttnArgs)]
     L.slm_paged_kv_varlen_mha_decode_kernel.restype = C.c_int32
     L.slm_paged_kv_varlen_mha_decode_kernel.argtypes = [C.POINTER(AttnArgs)]
+    L.slm_build_step_inputs.restype = C.c_int
+    L.slm_build_step_inputs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
     L.slm_set_kv_cache.restype = C.c_int
     L.slm_set_kv_cache.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                    C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,

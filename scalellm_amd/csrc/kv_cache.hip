@@ -64,6 +64,101 @@ __global__ void __launch_bounds__(256) decode_advance_kernel(
   kv_cu_lens[b] += b;  // b = 0 .. n_seqs: every sequence before this offset grew by one token
 }
 
+// Step-input build for ANY batch shape (beyond steady decode): prefix sums of the
+// per-sequence lengths, then positions and cache slots of every new token.  ONE workgroup: a step
+// has at most a few thousand sequences and tokens, the work is two scans and a fill (microseconds),
+// and a single workgroup needs no cross-workgroup ordering between the scan and the fill.
+constexpr int BSI_THREADS = 1024;
+__global__ void __launch_bounds__(BSI_THREADS) build_step_inputs_kernel(
+    const int32_t* __restrict__ q_lens, int32_t* __restrict__ kv_cached,
+    const int32_t* __restrict__ block_table, const int32_t* __restrict__ block_cu_lens, int32_t n_seqs,
+    int32_t shift, int32_t mask, int32_t n_tokens_padded, int32_t commit, int32_t* __restrict__ positions,
+    int32_t* __restrict__ q_cu_lens, int32_t* __restrict__ kv_cu_lens, int32_t* __restrict__ new_cache_slots,
+    int32_t* __restrict__ overflow_flag) {
+  __shared__ int32_t wsum_q[BSI_THREADS / 64], wsum_kv[BSI_THREADS / 64];
+  __shared__ int32_t carry[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    carry[0] = 0;
+    carry[1] = 0;
+    q_cu_lens[0] = 0;
+    kv_cu_lens[0] = 0;
+  }
+  __syncthreads();
+  // ---- inclusive scans of q and (cached + q) over the sequences, BSI_THREADS at a time
+  for (int32_t base = 0; base < n_seqs; base += BSI_THREADS) {
+    const int32_t b = base + tid;
+    int32_t q = 0, kv = 0;
+    if (b < n_seqs) {
+      q = q_lens[b];
+      q = q > 0 ? q : 0;
+      kv = kv_cached[b] + q;
+    }
+    int32_t sq = q, skv = kv;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {  // wave-level inclusive scan
+      const int32_t oq = __shfl_up(sq, d, 64), okv = __shfl_up(skv, d, 64);
+      if (lane >= d) {
+        sq += oq;
+        skv += okv;
+      }
+    }
+    if (lane == 63) {
+      wsum_q[wave] = sq;
+      wsum_kv[wave] = skv;
+    }
+    __syncthreads();
+    int32_t pq = carry[0], pkv = carry[1];
+    for (int w = 0; w < wave; ++w) {
+      pq += wsum_q[w];
+      pkv += wsum_kv[w];
+    }
+    if (b < n_seqs) {
+      q_cu_lens[b + 1] = pq + sq;
+      kv_cu_lens[b + 1] = pkv + skv;
+    }
+    __syncthreads();
+    if (tid == BSI_THREADS - 1) {
+      carry[0] = pq + sq;
+      carry[1] = pkv + skv;
+    }
+    __syncthreads();
+  }
+  const int32_t n_tok = carry[0];
+  // ---- fill: token t belongs to the sequence b with q_cu[b] <= t < q_cu[b + 1] (this workgroup's own
+  // writes: visible after the barriers above)
+  for (int32_t t = tid; t < n_tokens_padded; t += BSI_THREADS) {
+    if (t >= n_tok) {  // graph padding rows (batch.cpp:219-244): position 0, slot 0
+      positions[t] = 0;
+      new_cache_slots[t] = 0;
+      continue;
+    }
+    int32_t lo = 0, hi = n_seqs;
+    while (lo < hi) {
+      const int32_t mid = (lo + hi) >> 1;
+      if (q_cu_lens[mid + 1] <= t) lo = mid + 1; else hi = mid;
+    }
+    const int32_t b = lo;
+    const int32_t j = kv_cached[b] + (t - q_cu_lens[b]);  // position in the sequence (batch.cpp:155)
+    const int32_t bbase = block_cu_lens[b];
+    const int32_t nblk = block_cu_lens[b + 1] - bbase;
+    int32_t blk = j >> shift;
+    if (blk >= nblk) {  // the host has not appended the block yet
+      if (overflow_flag) atomicOr(overflow_flag, 1);
+      blk = nblk > 0 ? nblk - 1 : 0;
+    }
+    positions[t] = j;
+    new_cache_slots[t] = block_table[bbase + blk] + (j & mask);  // sequence.cpp:303-317
+  }
+  if (commit) {  // Sequence::commit_kv_cache (batch.cpp:197): after every read of kv_cached above
+    __syncthreads();
+    for (int32_t b = tid; b < n_seqs; b += BSI_THREADS) {
+      const int32_t q = q_lens[b];
+      if (q > 0) kv_cached[b] += q;
+    }
+  }
+}
+
 }  // namespace slm
 
 using namespace slm;
@@ -119,5 +214,23 @@ extern "C" SLM_API int slm_decode_advance(int32_t* positions, int32_t* kv_cu_len
   hipLaunchKernelGGL(decode_advance_kernel, grid, blk, 0, st, positions, kv_cu_lens, new_cache_slots,
                      block_table, block_cu_lens, n_seqs, ilog2(block_size), block_size - 1,
                      overflow_flag);
+  return hip_check_launch();
+}
+
+extern "C" SLM_API int slm_build_step_inputs(const int32_t* q_lens, int32_t* kv_cached, const int32_t* block_table,
+                                             const int32_t* block_cu_lens, int32_t n_seqs, int32_t block_size,
+                                             int32_t n_tokens_padded, int32_t commit, int32_t* positions,
+                                             int32_t* q_cu_lens, int32_t* kv_cu_lens, int32_t* new_cache_slots,
+                                             int32_t* overflow_flag, void* stream) {
+  if (n_seqs < 0 || n_tokens_padded < 0) return SLM_ERR_INVALID_ARG;
+  if (!q_cu_lens || !kv_cu_lens) return SLM_ERR_INVALID_ARG;
+  if (n_seqs > 0 && (!q_lens || !kv_cached || !block_table || !block_cu_lens)) return SLM_ERR_INVALID_ARG;
+  if (n_tokens_padded > 0 && (!positions || !new_cache_slots)) return SLM_ERR_INVALID_ARG;
+  if (block_size <= 0 || (block_size & (block_size - 1))) return SLM_ERR_UNSUPPORTED;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hip_clear_error();
+  hipLaunchKernelGGL(build_step_inputs_kernel, dim3(1), dim3(BSI_THREADS), 0, st, q_lens, kv_cached, block_table,
+                     block_cu_lens, n_seqs, ilog2(block_size), block_size - 1, n_tokens_padded, commit, positions,
+                     q_cu_lens, kv_cu_lens, new_cache_slots, overflow_flag);
   return hip_check_launch();
 }

@@ -322,6 +322,37 @@ def decode_advance(positions: torch.Tensor, kv_cu_lens: torch.Tensor, new_cache_
                                _stream()), "slm_decode_advance")
 
 
+def build_step_inputs(q_lens: torch.Tensor, kv_cached: torch.Tensor, block_table: torch.Tensor,
+                      block_cu_lens: torch.Tensor, block_size: int, positions: torch.Tensor,
+                      q_cu_lens: torch.Tensor, kv_cu_lens: torch.Tensor, new_cache_slots: torch.Tensor,
+                      commit: bool = True, overflow_flag: torch.Tensor | None = None) -> None:
+    """Device-side input build for ANY batch (SURVEY 8f f4 beyond steady decode): q_cu_seq_lens,
+    kv_cu_seq_lens, positions and new_cache_slots of a step from the per-sequence (new tokens,
+    tokens cached) arrays and the persistent block table -- the integer work of
+    Batch::prepare_model_input (engine/batch.cpp:97-255) without its per-token host loops and
+    the H2D copy of the flattened table.  positions / new_cache_slots may be longer than the step's
+    tokens (graph padding rows get position 0, slot 0).  commit: kv_cached += q_lens afterwards
+    (Sequence::commit_kv_cache)."""
+    L = _lib.lib()
+    ts = [q_lens, kv_cached, block_table, block_cu_lens, positions, q_cu_lens, kv_cu_lens, new_cache_slots]
+    if overflow_flag is not None:
+        ts.append(overflow_flag)
+    _require_gpu(*ts)
+    for t in ts:
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise SlmError("build_step_inputs: all index tensors must be contiguous int32")
+    n = q_lens.numel()
+    if kv_cached.numel() != n or block_cu_lens.numel() != n + 1 or q_cu_lens.numel() != n + 1 or \
+            kv_cu_lens.numel() != n + 1 or new_cache_slots.numel() != positions.numel():
+        raise SlmError("build_step_inputs: inconsistent sizes")
+    check(L.slm_build_step_inputs(q_lens.data_ptr(), kv_cached.data_ptr(), block_table.data_ptr(),
+                                  block_cu_lens.data_ptr(), n, block_size, positions.numel(), 1 if commit else 0,
+                                  positions.data_ptr(), q_cu_lens.data_ptr(), kv_cu_lens.data_ptr(),
+                                  new_cache_slots.data_ptr(),
+                                  overflow_flag.data_ptr() if overflow_flag is not None else None, _stream()),
+          "slm_build_step_inputs")
+
+
 # ---------------------------------------------------------------------------------------
 # int4 (AWQ / GPTQ) prepack + GEMM
 # ---------------------------------------------------------------------------------------

@@ -219,6 +219,20 @@ def test_w8_plane_form_host_side():
     assert L.slm_w8_prepack_sz(_lib.SLM_W4_AWQ, None, 256, 128, 64, 128, 1, 256, None) == -2
 
 
+def test_build_step_inputs_validates_before_any_launch():
+    """slm_build_step_inputs(q_lens, kv_cached, block_table, block_cu_lens, n_seqs, block_size,
+    n_tokens_padded, commit, positions, q_cu_lens, kv_cu_lens, new_cache_slots, overflow_flag, stream)."""
+    L = _lib.lib()
+    f = L.slm_build_step_inputs
+    assert f(256, 512, 768, 1024, -1, 16, 8, 1, 2048, 4096, 8192, 16384, None, None) == -1     # n_seqs < 0
+    assert f(256, 512, 768, 1024, 4, 16, -1, 1, 2048, 4096, 8192, 16384, None, None) == -1     # padded < 0
+    assert f(None, 512, 768, 1024, 4, 16, 8, 1, 2048, 4096, 8192, 16384, None, None) == -1     # NULL q_lens
+    assert f(256, 512, 768, 1024, 4, 16, 8, 1, None, 4096, 8192, 16384, None, None) == -1      # NULL positions
+    assert f(256, 512, 768, 1024, 4, 16, 8, 1, 2048, None, 8192, 16384, None, None) == -1      # NULL q_cu_lens
+    assert f(256, 512, 768, 1024, 4, 12, 8, 1, 2048, 4096, 8192, 16384, None, None) == -2      # block size 12
+    assert f(256, 512, 768, 1024, 4, 0, 8, 1, 2048, 4096, 8192, 16384, None, None) == -2
+
+
 def test_deferred_splitk_reduce_host_side():
     """SLM_W4_DEFER_REDUCE: whether a call defers is a pure function of its argument block, and
     slm_rms_norm_splitk validates before any launch."""

@@ -120,3 +120,67 @@ def test_decode_advance_bit_exact_and_graph_replay():
     for _ in range(80):
         kernels.decode_advance(pos_d, kcu_d, slots_d, table_d, bcu_d, B, flag)
     assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("n_seqs,B", [(13, 8), (300, 16), (2500, 16)])
+def test_build_step_inputs_bit_exact_mixed_batches_and_graph_replay(n_seqs, B):
+    """f4 beyond steady decode (slm_build_step_inputs): the integer inputs of mixed steps (prefill
+    chunks, verify rows, decode rows, sequences without budget) built on the device == the oracle's
+    restatement of Batch::prepare_model_input, step after step with the cache positions committed
+    on the device; padding rows zeroed; a captured launch replays on new per-sequence lengths;
+    more sequences than one scan pass (2500 > 1024); a missing block raises the flag."""
+    from scalellm_amd import kernels
+    rng = np.random.default_rng(n_seqs)
+    total = rng.integers(5, 120, size=n_seqs)
+    nblk = (total + B - 1) // B
+    ids = rng.permutation(int(nblk.sum()) + 3)[:int(nblk.sum())].astype(np.int64)
+    table = (ids * B).astype(np.int32)
+    bcu = np.concatenate([[0], np.cumsum(nblk)]).astype(np.int32)
+    cached = np.zeros(n_seqs, np.int32)
+    T_pad = int(min(total.sum(), 40 * n_seqs)) + 7
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(DEV)  # noqa: E731
+    table_d, bcu_d, cached_d = dev(table), dev(bcu), dev(cached)
+    q_d = torch.zeros(n_seqs, dtype=torch.int32, device=DEV)
+    pos_d = torch.full((T_pad,), -7, dtype=torch.int32, device=DEV)
+    slots_d = torch.full((T_pad,), -7, dtype=torch.int32, device=DEV)
+    qcu_d = torch.full((n_seqs + 1,), -7, dtype=torch.int32, device=DEV)
+    kcu_d = torch.full((n_seqs + 1,), -7, dtype=torch.int32, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    graph = None
+    for step in range(6):
+        q = np.minimum(total - cached, rng.integers(0, 40, size=n_seqs)).astype(np.int32)
+        if step % 2 == 1:
+            q = np.minimum(q, 1)
+        q_d.copy_(dev(q))
+        if step == 2:   # from here on: the same launch, captured once, replayed on new lengths
+            graph = torch.cuda.CUDAGraph()
+            snap = cached_d.clone()
+            with torch.cuda.graph(graph):
+                kernels.build_step_inputs(q_d, cached_d, table_d, bcu_d, B, pos_d, qcu_d, kcu_d, slots_d,
+                                          commit=True, overflow_flag=flag)
+            cached_d.copy_(snap)   # (capture does not run the kernel, but keep the state explicit)
+        if graph is None:
+            kernels.build_step_inputs(q_d, cached_d, table_d, bcu_d, B, pos_d, qcu_d, kcu_d, slots_d,
+                                      commit=True, overflow_flag=flag)
+        else:
+            graph.replay()
+        torch.cuda.synchronize()
+        pos, qcu, kcu, slots, missing = oracle.build_step_inputs(q, cached, table, bcu, B, T_pad)
+        assert missing == 0 and int(flag.item()) == 0
+        np.testing.assert_array_equal(pos_d.cpu().numpy(), pos)
+        np.testing.assert_array_equal(slots_d.cpu().numpy(), slots)
+        np.testing.assert_array_equal(qcu_d.cpu().numpy(), qcu)
+        np.testing.assert_array_equal(kcu_d.cpu().numpy(), kcu)
+        cached = cached + q
+        np.testing.assert_array_equal(cached_d.cpu().numpy(), cached)   # committed on the device
+    # commit=False leaves kv_cached alone; a position past the sequence's blocks raises the flag
+    q = np.zeros(n_seqs, np.int32)
+    q[0] = 3
+    before = cached_d.clone()
+    cached_d[0] = int(nblk[0]) * B - 1
+    q_d.copy_(dev(q))
+    kernels.build_step_inputs(q_d, cached_d, table_d, bcu_d, B, pos_d, qcu_d, kcu_d, slots_d, commit=False,
+                              overflow_flag=flag)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1 and int(cached_d[0].item()) == int(nblk[0]) * B - 1
+    assert torch.equal(cached_d[1:], before[1:])

@@ -190,6 +190,68 @@ def test_4bit_entry_points_agree_with_the_generic_ones():
                                           oracle.gptq_dequant(c["qweight"], c["qzeros"], sc, gs, g_idx))
 
 
+def _ref_prepare_model_input(seqs, B):
+    """Batch::prepare_model_input (engine/batch.cpp:97-255) restated line by line on Python lists:
+    seqs = [(n_kv_cache_tokens, q_seq_len, [block ids])]; returns the integer tensors it builds."""
+    positions, slots, cu, q_cu, table, cu_blk = [], [], [0], [0], [], [0]
+    for n_kv, q, blocks in seqs:
+        if q == 0:      # "no token budget left for the prefill sequence": dropped from the batch (:113-117)
+            continue
+        seq_len = n_kv + q
+        cu.append(cu[-1] + seq_len)
+        q_cu.append(q_cu[-1] + q)
+        for j in range(n_kv, seq_len):
+            positions.append(j)                                  # :155
+            slots.append(blocks[j // B] * B + j % B)             # Sequence::kv_cache_slots, sequence.cpp:303-317
+        table.extend(b * B for b in blocks)                      # :206-209
+        cu_blk.append(len(table))
+    return positions, slots, cu, q_cu, table, cu_blk
+
+
+def test_build_step_inputs_matches_prepare_model_input_on_mixed_batches():
+    """f4 for any batch: the oracle's step-input build equals the reference's host loops on mixed
+    batches (prefill chunks, k + 1 verify rows, decode rows; budgets that stop a chunk early), step
+    after step with the cache positions committed in between; sequences without budget keep an
+    EMPTY row range (the one documented difference: the reference drops them)."""
+    rng = np.random.default_rng(11)
+    B = 8
+    n = 13
+    total = rng.integers(5, 300, size=n)                       # tokens each sequence will have in the end
+    cached = np.zeros(n, np.int64)
+    blocks = []
+    ids = rng.permutation(int(sum((t + B - 1) // B for t in total)) + 5)
+    off = 0
+    for t in total:
+        nb = int((t + B - 1) // B)
+        blocks.append([int(x) for x in ids[off:off + nb]])
+        off += nb
+    bcu = np.concatenate([[0], np.cumsum([len(b) for b in blocks])]).astype(np.int32)
+    table = np.asarray([x * B for b in blocks for x in b], np.int32)
+    for step in range(12):
+        q = np.minimum(total - cached, rng.integers(0, 70, size=n))    # 0 = no budget this step
+        if step % 3 == 2:
+            q = np.minimum(q, 1)                                       # a decode-ish step
+        seqs = [(int(cached[i]), int(q[i]), blocks[i]) for i in range(n)]
+        pos_r, slots_r, cu_r, qcu_r, table_r, cublk_r = _ref_prepare_model_input(seqs, B)
+        T = int(q.sum())
+        pos, qcu, kcu, slots, missing = oracle.build_step_inputs(q, cached, table, bcu, B, T + 5)
+        assert missing == 0
+        np.testing.assert_array_equal(pos[:T], np.asarray(pos_r, np.int32))
+        np.testing.assert_array_equal(slots[:T], np.asarray(slots_r, np.int32))
+        assert not pos[T:].any() and not slots[T:].any()              # padding rows (:219-244)
+        live = q > 0
+        np.testing.assert_array_equal(np.diff(qcu)[live], np.diff(np.asarray(qcu_r)))
+        np.testing.assert_array_equal(np.diff(kcu)[live], np.diff(np.asarray(cu_r)))
+        np.testing.assert_array_equal(np.diff(qcu)[~live], 0)
+        np.testing.assert_array_equal(np.diff(kcu)[~live], cached[~live])
+        # the reference's table holds the live sequences' blocks only; ours is the persistent one
+        assert table_r == [int(x) for i in range(n) if live[i] for x in table[bcu[i]:bcu[i + 1]]]
+        cached = cached + q
+    # a position without a block is counted, not silently mis-addressed
+    _, _, _, _, missing = oracle.build_step_inputs([3], [B * len(blocks[0]) - 1], table, bcu[:2], B, 3)
+    assert missing == 2
+
+
 def test_decode_advance_matches_a_full_host_rebuild():
     """f4: the incremental next-step inputs equal what the reference rebuilds from scratch every
     step (Batch::prepare_model_input, engine/batch.cpp:97-255): positions = tokens cached, slot =
