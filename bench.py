@@ -518,6 +518,22 @@ def main():
             first_tokens = static_tokens[:16].tolist()
     torch.cuda.synchronize()
 
+    def check_fused_reduce(where: str) -> None:
+        """A peer that never arrived raises a sticky error word instead of hanging the GPU (bounded
+        spins, csrc/allreduce.hip): fail loudly rather than time garbage -- every later launch
+        would sit out its own 20 s timeout."""
+        if custom_ar is None:
+            return
+        err = torch.tensor([int(custom_ar.error())], dtype=torch.int32)
+        if torch.distributed.get_backend() == "nccl":
+            err = err.to(device)
+        torch.distributed.all_reduce(err, op=torch.distributed.ReduceOp.MAX)
+        if int(err.item()) != 0:
+            raise SystemExit(f"[bench] rank {rank}: fused xGMI all-reduce reported error bits {int(err.item()):#x} "
+                             f"{where}; rerun with SLM_CUSTOM_AR=0 for the RCCL path")
+
+    check_fused_reduce("after the warm-up steps")
+
     graph = None
     if world > 1 and custom_ar is not None:
         pass  # the step contains no RCCL / gloo collective at all: capture it as it is
@@ -567,6 +583,7 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    check_fused_reduce("during the timed steps")
     ms_per_step = elapsed / args.steps * 1e3
     tok_s = bs * args.steps / elapsed
 
