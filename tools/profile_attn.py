@@ -12,7 +12,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scalellm_amd import kernels  # noqa: E402
-from scalellm_amd.decode import make_decode_inputs, _rand_int4_linear  # noqa: E402
+from scalellm_amd.decode import make_batch_inputs, make_decode_inputs, _rand_int4_linear  # noqa: E402
 
 
 def main():
@@ -21,7 +21,13 @@ def main():
     dev = torch.device("cuda", 0)
     H, HKV = (int(x) for x in os.environ.get("HEADS", "32,8").split(","))
     D, B, L = 128, int(os.environ.get("BLOCK", "16")), int(os.environ.get("SEQLEN", "4096"))
-    tokens, positions, p, n_blocks = make_decode_inputs(bs, L, B, dev, seed=1)
+    if os.environ.get("RAGGED"):  # kv_len ~ U[2048, 4096], seed 1: the serving-shaped batch
+        import numpy as np
+        kv_lens = [int(x) for x in np.random.default_rng(1).integers(2048, 4097, size=bs)]
+        tokens, positions, p, n_blocks = make_batch_inputs([1] * bs, kv_lens, B, dev, seed=1)
+        print("RAGGED kv tokens", sum(kv_lens), flush=True)
+    else:
+        tokens, positions, p, n_blocks = make_decode_inputs(bs, L, B, dev, seed=1)
     g = torch.Generator(device=dev).manual_seed(0)
     q = torch.randn(bs, H, D, device=dev, dtype=torch.bfloat16, generator=g)
     kc = torch.randn(n_blocks * B, HKV, D, device=dev, dtype=torch.bfloat16, generator=g)
