@@ -169,7 +169,9 @@ PYBIND11_MODULE(_slm_shim, m) {
            py::arg("g_idx"), py::arg("group_size"), py::arg("bits") = 4)
       .def("forward", &slm::W4Linear::forward, py::arg("input"), py::arg("bias") = std::nullopt,
            py::arg("out") = std::nullopt)
-      .def("dequantize", &slm::W4Linear::dequantize);
+      .def("dequantize", &slm::W4Linear::dequantize)
+      .def("in_features", &slm::W4Linear::in_features)
+      .def("out_features", &slm::W4Linear::out_features);
   m.def("process_group_test", [](int n_devices) {
     // The reference's ProcessGroupTest (src/model_parallel/process_group_test.cpp:48-171) in its
     // own shape: ONE process, one communicator per GPU created together (ncclCommInitAll), one

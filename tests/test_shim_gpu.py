@@ -104,6 +104,30 @@ def test_shim_w4linear(shim, fmt):
     assert np.abs(out - ref).mean() / np.abs(ref).mean() < 8e-3
 
 
+@pytest.mark.parametrize("fmt,act", [("awq", False), ("gptq", False), ("gptq", True)])
+def test_shim_w4linear_8bit(shim, fmt, act):
+    """slm::W4Linear with bits = 8 (two int4 planes, include/slm_hip.h section 3b), incl. act-order: the
+    same bits as the Python mirror's kernels.{awq,gptq}_repack(bits=8) + gptq_gemm, and the oracle."""
+    from scalellm_amd import kernels
+    case = helpers.make_quant8_case(9, 512, 256, 128, fmt, "bf16", act_order=act)
+    qweight = torch.from_numpy(case["qweight"]).to(DEV)
+    qzeros = torch.from_numpy(case["qzeros"]).to(DEV)
+    scales = torch.from_numpy(case["scales_bits"].view(np.int16)).to(DEV).view(torch.bfloat16)
+    g_idx = torch.from_numpy(case["g_idx"]).to(DEV) if case["g_idx"] is not None else None
+    lin = shim.W4Linear(fmt, qweight, qzeros, scales, g_idx, 128, 8)
+    assert lin.in_features() == 512 and lin.out_features() == 256
+    a = torch.randn(40, 512, device=DEV, dtype=torch.bfloat16)
+    bias = torch.randn(256, device=DEV, dtype=torch.bfloat16)
+    c = lin.forward(a, bias)
+    packed = helpers.pack_case8(case, "bf16")
+    c_py = torch.empty_like(c)
+    kernels.gptq_gemm(a, packed, c_py, bias)
+    torch.cuda.synchronize()
+    assert torch.equal(c, c_py)
+    ref = oracle.gemm_f32(a.float().cpu().numpy(), helpers.dense_weight8(case)) + bias.float().cpu().numpy()[None]
+    assert np.abs(c.float().cpu().numpy() - ref).mean() / np.abs(ref).mean() < 8e-3
+
+
 def test_shim_process_group_rccl_single_gpu(shim):
     # Worker::process_group_test (engine/worker.cpp:111-123): all-reduce + all-gather smoke test,
     # world size = the GPUs of this box (1): RCCL comm init, collectives on the current stream
