@@ -162,6 +162,32 @@ def test_per_channel_scales_with_k_not_a_power_of_two(K, fmt):
         assert _rel_err(c.float().cpu().numpy(), ref) < GEMM_TOL["bf16"], (K, fmt, M)
 
 
+@pytest.mark.parametrize("M", [8, 32, 256])
+def test_8bit_weights_with_a_deferred_splitk_reduce(M):
+    """The plane form runs through the column gather (perm2) -- also under SLM_W4_DEFER_REDUCE: a split-K
+    call leaves its fp32 slabs for slm_rms_norm_splitk; bit-identical to GEMM -> reduce -> rms_norm."""
+    from scalellm_amd import kernels
+    K, N = 4096, 4096
+    case = helpers.make_quant8_case(33 + M, K, N, 128, "awq", "bf16")
+    packed = helpers.pack_case8(case, "bf16")
+    g = torch.Generator(device=DEV).manual_seed(M)
+    a = torch.randn(M, K, device=DEV, dtype=torch.bfloat16, generator=g)
+    w = (1 + 0.1 * torch.randn(N, device=DEV, generator=g)).to(torch.bfloat16)
+    res0 = torch.randn(M, N, device=DEV, dtype=torch.bfloat16, generator=g)
+    c = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    assert not kernels.gptq_gemm(a, packed, c)
+    out_ref, res_ref = torch.empty_like(c), res0.clone()
+    kernels.rms_norm(out_ref, c, w, 1e-5, res_ref)
+    c2 = torch.full_like(c, float("nan"))
+    h = kernels.gptq_gemm(a, packed, c2, defer_reduce=True)
+    out, res = torch.empty_like(c), res0.clone()
+    kernels.rms_norm(out, c2, w, 1e-5, res, partials=h)
+    torch.cuda.synchronize()
+    if not h:
+        assert torch.equal(c2, c)
+    assert torch.equal(out, out_ref) and torch.equal(res, res_ref)
+
+
 def test_8bit_paired_gate_up_fuses_silu_mul():
     """SLM_W4_PAIRED composes with the plane form: silu(gate) * up in the GEMM epilogue is
     bit-identical to the unfused GEMM + slm_silu_mul."""
