@@ -52,24 +52,26 @@ class LlamaShape:
                           n_layers=2, vocab=1024, max_position=512)
 
 
-def _rand_int4_linear(gen, K, N, group_size, fmt, dtype, device, sym=False, desc_act=False):
-    """Random layer in CHECKPOINT format (AWQ [K,N/8] / GPTQ [K/8,N]); random bits = uniform nibbles.
+def _rand_int4_linear(gen, K, N, group_size, fmt, dtype, device, sym=False, desc_act=False, bits=4):
+    """Random layer in CHECKPOINT format (AWQ [K,N/8] / GPTQ [K/8,N]); random bits = uniform nibbles
+    (bits = 8: [K, N/4] / [K/4, N], uniform bytes; scales 16x smaller so the weights have the same spread).
     sym: GPTQ symmetric quantisation -- every stored zero point is 7 (zero = stored + 1 = 8,
     qlinear_impl.cpp:45), what `sym: true` GPTQ checkpoints carry.
     desc_act (GPTQ): an act-order checkpoint -- g_idx[k] = scale group of row k, a random
     assignment with exactly group_size rows per group (what `desc_act: true` quantisation leaves)."""
     G = K // group_size
+    per = 32 // bits  # values per int32
     if fmt == "awq":
-        qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, (K, N // 8), device=device, generator=gen,
+        qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, (K, N // per), device=device, generator=gen,
                                 dtype=torch.int64).to(torch.int32)
     else:
-        qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // 8, N), device=device, generator=gen,
+        qweight = torch.randint(-2 ** 31, 2 ** 31 - 1, (K // per, N), device=device, generator=gen,
                                 dtype=torch.int64).to(torch.int32)
-    qzeros = torch.randint(-2 ** 31, 2 ** 31 - 1, (G, N // 8), device=device, generator=gen,
+    qzeros = torch.randint(-2 ** 31, 2 ** 31 - 1, (G, N // per), device=device, generator=gen,
                            dtype=torch.int64).to(torch.int32)
     if sym:
-        qzeros.fill_(0x77777777)
-    scales = (torch.rand(G, N, device=device, generator=gen) * 0.006 + 0.002).to(dtype)
+        qzeros.fill_(0x77777777 if bits == 4 else 0x7f7f7f7f)  # stored zero = 2^(bits-1) - 1
+    scales = ((torch.rand(G, N, device=device, generator=gen) * 0.006 + 0.002) * (1.0 if bits == 4 else 1 / 16)).to(dtype)
     ck = {"qweight": qweight, "qzeros": qzeros, "scales": scales}
     if desc_act and fmt == "gptq":
         order = torch.randperm(K, device=device, generator=gen)
@@ -79,24 +81,26 @@ def _rand_int4_linear(gen, K, N, group_size, fmt, dtype, device, sym=False, desc
     return ck
 
 
-def _shard_cols(ck, fmt, col_ranges):
+def _shard_cols(ck, fmt, col_ranges, bits=4):
     """Column-parallel shard of a checkpoint-format layer: concatenation of the given [n0, n1)
     column ranges (all multiples of 8) -- how LOAD_FUSED_WEIGHT / LOAD_SHARDED_WEIGHT slice dim 1
     (src/layers/linear/weight_utils.h:48-83, qkv_parallel_linear.cpp:20-60)."""
+    per = 32 // bits
+
     def cat(t, div):
         return torch.cat([t[:, a // div:b // div] for a, b in col_ranges], dim=1).contiguous()
-    out = {"qweight": cat(ck["qweight"], 8 if fmt == "awq" else 1), "qzeros": cat(ck["qzeros"], 8),
+    out = {"qweight": cat(ck["qweight"], per if fmt == "awq" else 1), "qzeros": cat(ck["qzeros"], per),
            "scales": cat(ck["scales"], 1)}
     if "g_idx" in ck:  # column-parallel: every rank holds all of K (qlinear_gptq_marlin_impl.cpp:150-165)
         out["g_idx"] = ck["g_idx"]
     return out
 
 
-def _shard_rows(ck, fmt, k0, k1, group_size):
+def _shard_rows(ck, fmt, k0, k1, group_size, bits=4):
     """Row-parallel shard [k0, k1) of K (multiples of the group size).  Act-order checkpoints: the
     rows of the shard belong to ANY group, so g_idx is sharded with the rows and the scale / zero
     tables stay whole (qlinear_gptq_marlin_impl.cpp:236-243 load_full_scales_, :270-276)."""
-    div = 1 if fmt == "awq" else 8
+    div = 1 if fmt == "awq" else 32 // bits
     if "g_idx" in ck:
         return {"qweight": ck["qweight"][k0 // div:k1 // div].contiguous(), "qzeros": ck["qzeros"],
                 "scales": ck["scales"], "g_idx": ck["g_idx"][k0:k1].contiguous()}
@@ -110,7 +114,7 @@ class LlamaDecodeStep:
                  parallel_args: Optional[ParallelArgs] = None, quant_method: str = "awq",
                  group_size: int = 128, dtype=torch.bfloat16, device="cuda", seed: int = 0,
                  kv_fill: str = "none", custom_allreduce=None, keep_checkpoint: bool = False,
-                 gptq_sym: bool = False, fuse_silu: bool = True, desc_act: bool = False):
+                 gptq_sym: bool = False, fuse_silu: bool = True, desc_act: bool = False, bits: int = 4):
         pa = parallel_args or ParallelArgs()
         # fuse_silu: the merged gate_up weight is packed paired and SiLU*mul runs in the GEMM
         # epilogue (identical bits; False keeps the separate kernels.silu_and_mul launch)
@@ -138,7 +142,7 @@ class LlamaDecodeStep:
         # tensor-parallel shard, so TP=N and TP=1 are the same model (tests compare them)
         gen = torch.Generator(device=self.device).manual_seed(seed * 1000 + 17)
         desc_act = desc_act and quant_method == "gptq"  # act-order GPTQ checkpoint (random g_idx)
-        qa = QuantArgs(quant_method=quant_method, bits=4, group_size=group_size,
+        qa = QuantArgs(quant_method=quant_method, bits=bits, group_size=group_size,
                        zero_point=(quant_method == "awq"), desc_act=desc_act)
         inv_freq = 1.0 / (shape.rope_theta ** (torch.arange(0, D, 2, dtype=torch.float32,
                                                               device=self.device) / D))
@@ -158,23 +162,23 @@ class LlamaDecodeStep:
                                                  act_mul="silu" if fuse_silu else None)
             L["down"] = RowParallelQLinear(inter, H, False, qa, True, pa, dtype, self.device)
             full = _rand_int4_linear(gen, H, q_full + 2 * kv_full, group_size, quant_method, dtype, self.device,
-                                     sym=gptq_sym and quant_method == "gptq", desc_act=desc_act)
+                                     sym=gptq_sym and quant_method == "gptq", desc_act=desc_act, bits=bits)
             shard = {
                 "qkv": _shard_cols(full, quant_method, [
                     (r * nh * D, (r + 1) * nh * D),
                     (q_full + kv_head0 * D, q_full + (kv_head0 + nkv) * D),
-                    (q_full + kv_full + kv_head0 * D, q_full + kv_full + (kv_head0 + nkv) * D)])}
+                    (q_full + kv_full + kv_head0 * D, q_full + kv_full + (kv_head0 + nkv) * D)], bits)}
             full = _rand_int4_linear(gen, q_full, H, group_size, quant_method, dtype, self.device,
-                                     sym=gptq_sym and quant_method == "gptq", desc_act=desc_act)
-            shard["o"] = _shard_rows(full, quant_method, r * nh * D, (r + 1) * nh * D, group_size)
+                                     sym=gptq_sym and quant_method == "gptq", desc_act=desc_act, bits=bits)
+            shard["o"] = _shard_rows(full, quant_method, r * nh * D, (r + 1) * nh * D, group_size, bits)
             full = _rand_int4_linear(gen, H, 2 * inter, group_size, quant_method, dtype, self.device,
-                                     sym=gptq_sym and quant_method == "gptq", desc_act=desc_act)
+                                     sym=gptq_sym and quant_method == "gptq", desc_act=desc_act, bits=bits)
             shard["gate_up"] = _shard_cols(full, quant_method, [
                 (r * inter // tp, (r + 1) * inter // tp),
-                (inter + r * inter // tp, inter + (r + 1) * inter // tp)])
+                (inter + r * inter // tp, inter + (r + 1) * inter // tp)], bits)
             full = _rand_int4_linear(gen, inter, H, group_size, quant_method, dtype, self.device,
-                                     sym=gptq_sym and quant_method == "gptq", desc_act=desc_act)
-            shard["down"] = _shard_rows(full, quant_method, r * inter // tp, (r + 1) * inter // tp, group_size)
+                                     sym=gptq_sym and quant_method == "gptq", desc_act=desc_act, bits=bits)
+            shard["down"] = _shard_rows(full, quant_method, r * inter // tp, (r + 1) * inter // tp, group_size, bits)
             del full
             if keep_checkpoint:
                 self.ckpt.append({n: {k: v.clone() for k, v in shard[n].items()} for n in shard})

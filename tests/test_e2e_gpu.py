@@ -53,7 +53,7 @@ def _params(inp):
                             kv_max_seq_len=inp["max_kv"]))
 
 
-def _oracle_twin(model, quant_method, group_size, storage=None):
+def _oracle_twin(model, quant_method, group_size, storage=None, bits=4):
     """The same model as a LlamaDecodeStep(keep_checkpoint=True), rebuilt on the CPU from the
     CHECKPOINT-format int4 tensors: oracle.{awq,gptq}_dequant = construct_weights
     (qlinear_impl.cpp:21-100), then fp32 matmul (:171-183)."""
@@ -65,8 +65,8 @@ def _oracle_twin(model, quant_method, group_size, storage=None):
         for name, t in ck.items():
             qw, qz = t["qweight"].cpu().numpy(), t["qzeros"].cpu().numpy()
             sc = f(t["scales"].to(model.dtype))   # scales as the layer rounds them to T
-            W[name] = (oracle.awq_dequant(qw, qz, sc, group_size) if quant_method == "awq"
-                       else oracle.gptq_dequant(qw, qz, sc, group_size))
+            W[name] = (oracle.awq_dequant(qw, qz, sc, group_size, bits=bits) if quant_method == "awq"
+                       else oracle.gptq_dequant(qw, qz, sc, group_size, bits=bits))
         L = model.layers[li]
         W["in_norm"], W["post_norm"] = f(L["in_norm"]), f(L["post_norm"])
         layers.append(W)
@@ -86,15 +86,21 @@ def _llama_cases():
     gqa8 = LlamaShape(hidden=256, n_heads=16, n_kv_heads=2, head_dim=64, intermediate=512,
                       n_layers=2, vocab=1024, max_position=512)
     return {"tiny-awq": (LlamaShape.tiny(), "awq", 128, [37, 45, 5, 18]),
+            # bits = 8 (two int4 planes): the whole step -- norm prologue off (gather path), deferred
+            # reduces, paired gate|up -- on 8-bit checkpoints
+            "tiny-awq-8bit": (LlamaShape.tiny(), "awq", 128, [37, 45, 5, 18]),
+            "tiny-gptq-g64-8bit": (LlamaShape.tiny(), "gptq", 64, [37, 45, 5, 18]),
             "tiny-gptq-g64": (LlamaShape.tiny(), "gptq", 64, [37, 45, 5, 18]),
             "8b-shaped-2-layers-awq": (shaped_8b, "awq", 128, [23, 45, 12]),
             "tiny-gqa8-awq": (gqa8, "awq", 128, [9, 26] + [3 + (7 * i) % 11 for i in range(31)])}
 
 
-@pytest.mark.parametrize("name", ["tiny-awq", "tiny-gptq-g64", "8b-shaped-2-layers-awq", "tiny-gqa8-awq"])
+@pytest.mark.parametrize("name", ["tiny-awq", "tiny-gptq-g64", "8b-shaped-2-layers-awq", "tiny-gqa8-awq",
+                                  "tiny-awq-8bit", "tiny-gptq-g64-8bit"])
 def test_llama_prefill_then_decode_logits_match_oracle(name):
     from scalellm_amd.decode import LlamaDecodeStep
     shape, quant, gs, prompt_lens = _llama_cases()[name]
+    bits = 8 if name.endswith("8bit") else 4
     B, n_decode = 16, 3
     seqs = Sequences(prompt_lens, n_decode + 1, B, shape.vocab, seed=7)
     # schedule: step 0 prefills every prompt, except that sequence 1 is CHUNKED (first 20 tokens
@@ -105,9 +111,10 @@ def test_llama_prefill_then_decode_logits_match_oracle(name):
     steps = [first, [1 if i != 1 else prompt_lens[1] - 20 for i in range(len(prompt_lens))]]
     steps += [[1] * len(prompt_lens)] * n_decode
     model = LlamaDecodeStep(shape, sum(prompt_lens) + 8, seqs.n_blocks, B, quant_method=quant,
-                            group_size=gs, dtype=torch.bfloat16, device=DEV, seed=3, keep_checkpoint=True)
-    ref_model = _oracle_twin(model, quant, gs)                       # the reference CPU path: fp32
-    twin_model = _oracle_twin(model, quant, gs, storage="bf16")      # + the GPU path's storage roundings
+                            group_size=gs, dtype=torch.bfloat16, device=DEV, seed=3, keep_checkpoint=True,
+                            bits=bits)
+    ref_model = _oracle_twin(model, quant, gs, bits=bits)                   # the reference CPU path: fp32
+    twin_model = _oracle_twin(model, quant, gs, storage="bf16", bits=bits)  # + the GPU path's storage roundings
     agree = total = 0
     rels = []
     for si, new_lens in enumerate(steps):
@@ -119,7 +126,9 @@ def test_llama_prefill_then_decode_logits_match_oracle(name):
         ref = ref_model.forward(inp)
         a, n, rel = check_logits(got, ref, 3e-2, f"{name} step {si} (q_lens {new_lens}) vs fp32 oracle")
         agree, total = agree + a, total + n
-        _, _, rel_t = check_logits(got, twin_model.forward(inp), 1.5e-2,
+        # (8 bits: the twin rounds s (q - z) to bf16 once, the large-M kernels round each int4 plane's
+        # value -- two roundings: a slightly wider bound)
+        _, _, rel_t = check_logits(got, twin_model.forward(inp), 1.5e-2 if bits == 4 else 2e-2,
                                    f"{name} step {si} (q_lens {new_lens}) vs bf16-storage twin")
         rels.append((round(rel, 5), round(rel_t, 5)))
         seqs.advance(new_lens)
