@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, fused_ar=False, desc_act=False):
+def _worker(rank, world, port, q, fused_ar=False, desc_act=False, bits=4):
     try:
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                           MASTER_PORT=str(port), LOCAL_RANK="0", SLM_DIST_BACKEND="gloo")
@@ -41,6 +41,8 @@ def _worker(rank, world, port, q, fused_ar=False, desc_act=False):
             ar = try_create_xgmi_allreduce(rank, world, bs, shape.hidden, torch.bfloat16, dev)
             assert ar is not None, "fused all-reduce failed its self-test"
         quant = dict(quant_method="gptq", desc_act=True) if desc_act else {}
+        if bits != 4:
+            quant["bits"] = bits
         tp = LlamaDecodeStep(shape, bs, n_blocks, B, pa, dtype=torch.bfloat16, device=dev, seed=5,
                              kv_fill="consistent", custom_allreduce=ar, **quant)
         logits_tp = tp.forward(tokens, positions, params, return_logits=True).float().cpu()
@@ -108,6 +110,26 @@ def test_tp2_act_order_gptq_matches_tp1_on_one_gpu():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, False, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=30)
+    assert all("fail" not in r for r in res), res
+    r0 = next(r for r in res if r["rank"] == 0)
+    assert r0["err"] <= 0.05 * r0["scale"] + 1e-3, r0
+    assert r0["agree"] >= 0.8, r0
+
+
+@pytest.mark.timeout(300)
+def test_tp2_8bit_weights_match_tp1_on_one_gpu():
+    """bits = 8 under TP = 2: the 4-per-int32 checkpoint tensors are sharded on dim 1 (column-parallel:
+    qweight columns for AWQ, N/4 words of qzeros) and dim 0 (row-parallel: K/4 words for GPTQ), each shard
+    packed as two int4 planes.  (Act-order row shards with uneven groups stay 4-bit only.)"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, False, False, 8)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(world)]
