@@ -169,7 +169,8 @@ def measure_gemm(model, T):
     """int4 GEMM TFLOP/s of the largest layer GEMM (gate_up) at M = batch tokens (hipGraph of 20
     launches between HIP events)."""
     L = model.layers[0]["gate_up"]
-    x = torch.randn(T, L._packed.K, device=model.device, dtype=model.dtype)
+    kdim = L._packed.k_src  # (8-bit weights: the packed form has 2 x k_src rows, two int4 planes)
+    x = torch.randn(T, kdim, device=model.device, dtype=model.dtype)
     out = torch.empty(T, L._packed.N, device=model.device, dtype=model.dtype)
     n = 20
     for _ in range(3):
@@ -187,10 +188,10 @@ def measure_gemm(model, T):
     e1.record()
     e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / n
-    flops = 2.0 * T * L._packed.K * L._packed.N
+    flops = 2.0 * T * kdim * L._packed.N
     # context only (not on the product path): the vendor library's DENSE bf16 GEMM of the same shape
     # on the same GPU, timed the same way -- what "MFMA-bound" means in practice on this box
-    wd = torch.randn(L._packed.K, L._packed.N, device=model.device, dtype=model.dtype)
+    wd = torch.randn(kdim, L._packed.N, device=model.device, dtype=model.dtype)
     for _ in range(3):
         torch.matmul(x, wd, out=out)
     torch.cuda.synchronize()
@@ -206,7 +207,7 @@ def measure_gemm(model, T):
     e1.synchronize()
     us_dense = e0.elapsed_time(e1) * 1e3 / n
     del wd
-    return dict(shape=[T, L._packed.K, L._packed.N], us=round(us, 2),
+    return dict(shape=[T, kdim, L._packed.N], us=round(us, 2),
                 tflops=round(flops / us / 1e6, 1),
                 frac_of_bf16_mfma_peak=round(flops / us / 1e6 / MFMA_BF16_PEAK_TFLOPS, 4),
                 hipblaslt_dense_bf16_same_shape_tflops=round(flops / us_dense / 1e6, 1))
@@ -421,6 +422,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bits", type=int, default=4, choices=[4, 8], help="weight bits of the quantised linears "
+                    "(8 = the reference's num_bits = 8 path: two int4 planes on the int4 kernels; not the BASELINE metric)")
     ap.add_argument("--model", default="8b", choices=["8b", "70b"], help="8b = Llama-3-8B-shaped, "
                     "AWQ int4 g128, bs=256 (BASELINE.json metric configuration, configs[1]/[2]); 70b = "
                     "Llama-3-70B-shaped (in-tree defaults models/meta/llama.h:348-362), GPTQ symmetric "
@@ -493,7 +496,7 @@ def main():
             log=lambda m: print(f"[bench] {m}", file=sys.stderr))
     model = LlamaDecodeStep(shape, bs, n_blocks, B, pa, quant_method=quant, group_size=128,
                             dtype=torch.bfloat16, device=device, seed=0, kv_fill=args.kv_fill,
-                            custom_allreduce=custom_ar, gptq_sym=gptq_sym)
+                            custom_allreduce=custom_ar, gptq_sym=gptq_sym, bits=args.bits)
     model.reserve_workspaces(bs, L)
     torch.cuda.synchronize()
     t_init = time.perf_counter() - t_init
@@ -621,11 +624,12 @@ def main():
                       "HBM roofline + int4-GEMM TFLOP/s alongside)",
             "value": round(tok_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16 (int4 weights, fp32 accumulate)",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": f"bf16 (int{args.bits} weights, fp32 accumulate)",
             "data": "synthetic (seeded random weights, KV history and tokens)",
             "config": {"workload": f"llama3-{args.model}-shaped decode step: bs={bs}, kv_len={L}, q_len=1, "
                                    f"block_size={B}, {shape.n_layers} layers, {quant}"
-                                   f"{' (symmetric)' if gptq_sym and quant == 'gptq' else ''} int4 g128 "
+                                   f"{' (symmetric)' if gptq_sym and quant == 'gptq' else ''} int{args.bits} g128 "
                                    f"linears, bf16 KV cache, greedy",
                        "model": args.model,
                        "global_batch": bs, "seq_len": L,
