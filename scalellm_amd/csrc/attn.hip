@@ -592,11 +592,14 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
   pl->n_chunks = G / pl->gc;
   int hpw = 1;
   while (hpw * 2 <= upw && a->n_kv_heads % (hpw * 2) == 0) hpw *= 2;
-  // tiny decode batches: one KV head per wave load (4 consecutive slots of it instead of 4 heads of one
-  // slot) gives 4x the head groups, so the grid fills with a quarter of the KV splits and the combine
-  // merges a quarter of the partials: bs = 1 / 4 / 8 14.9 / 22.8 / 31.4 -> 13.6 / 21.0 / 29.7 us
-  // (32 q / 8 kv heads, 4 k context); from bs = 16 on the wide load is as good or better
-  if (a->max_q_len <= 1 && a->n_tokens <= 8) hpw = 1;
+  // decode batches up to 128 tokens: one KV head per wave load (4 consecutive slots of it instead of 4
+  // heads of one slot) gives 4x the head groups -- a finer grain for the workgroup count, so the grid
+  // fills whole rounds of the CUs with fewer KV splits and the combine merges fewer partials.
+  // Measured on one box, old -> new plan (32 q / 8 kv heads, 4 k context, uniform | ragged U[2048, 4096]):
+  // bs 1 14.9 -> 13.5 us, 4 22.4 -> 20.9, 8 31.5 -> 29.2, 12 46.1 -> 42.9, 24 81.0 -> 76.1 | 78.7 -> 71.0,
+  // 48 142.3 -> 139.8 | 128.6 -> 106.2, 64 176.2 -> 175.8 | 143.2 -> 136.4; equal within 2 % at 16, 32, 96,
+  // 128; above 128 tokens the wide load wins or ties (160: 430 vs 449 us)
+  if (a->max_q_len <= 1 && a->n_tokens <= 128) hpw = 1;
   pl->hpw_shift = ilog2(hpw);
   const int nhg = a->n_kv_heads / hpw;
   // Launch shape tuned on MI355X (tools/sweep_attn.py, profiles/attn_sweep_r1.md): 4 waves per
