@@ -599,9 +599,8 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
   // bs 1 14.9 -> 13.5 us, 4 22.4 -> 20.9, 8 31.5 -> 29.2, 12 46.1 -> 42.9, 24 81.0 -> 76.1 | 78.7 -> 71.0,
   // 48 142.3 -> 139.8 | 128.6 -> 106.2, 64 176.2 -> 175.8 | 143.2 -> 136.4; equal within 2 % at 16, 32, 96,
   // 128; above 128 tokens the wide load wins or ties (160: 430 vs 449 us)
+  const int hpw_max = hpw;
   if (a->max_q_len <= 1 && a->n_tokens <= 128) hpw = 1;
-  pl->hpw_shift = ilog2(hpw);
-  const int nhg = a->n_kv_heads / hpw;
   // Launch shape tuned on MI355X (tools/sweep_attn.py, profiles/attn_sweep_r1.md): 4 waves per
   // workgroup, ~256 workgroups per launch, >= 64 KV rows per split.
   pl->nw = tune_get(TUNE_ATTN_NW, 4);
@@ -610,15 +609,23 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
   const int64_t target_wgs = 256;
   const int64_t max_by_len = (a->max_kv_len > 64 ? a->max_kv_len : 64) / 64;
   int forced_splits = a->num_splits > 0 ? a->num_splits : tune_get(TUNE_ATTN_SPLITS, 0);
+  struct Shape { int hgw, n_splits; double fill; };
+  auto grid_fill = [&](int64_t w) {
+    return w > 0 ? (double)w / (double)(((w + target_wgs - 1) / target_wgs) * target_wgs) : 0.0;
+  };
+  // head groups per workgroup and KV splits for `hpw_c` KV heads per wave load
+  auto shape_for = [&](int hpw_c) -> Shape {
+  const int nhg = a->n_kv_heads / hpw_c;
   int hgw_cap = tune_get(TUNE_ATTN_HGW, pl->nw);
   int hgw = 1, n_splits = 1;
+  int64_t base = 1;
   for (int pass = 0; pass < 2; ++pass) {
     // LDS: table + HGW x per-wave exchange state, kept under the 64 KiB default dynamic limit
     hgw = 1;
     while (hgw * 2 <= pl->nw && hgw * 2 <= hgw_cap && nhg % (hgw * 2) == 0 &&
            (size_t)(hgw * 2) * state <= 48 * 1024)
       hgw *= 2;
-    const int64_t base = (int64_t)a->n_tokens * (nhg / hgw) * pl->n_chunks;
+    base = (int64_t)a->n_tokens * (nhg / hgw) * pl->n_chunks;
     int64_t want = (target_wgs + base - 1) / (base > 0 ? base : 1);
     if (want > max_by_len) want = max_by_len;
     if (want < 1) want = 1;
@@ -627,10 +634,7 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
       // workgroup-count quantisation: 288 workgroups on 256 CUs take as long as 512 (bs = 96:
       // 3 splits = 288 workgroups ran at 4.5 TB/s).  Look a few split counts further for one whose
       // grid fills whole rounds of the CUs (>= 90 %), and take the best seen otherwise.
-      auto fill = [&](int64_t sp) {
-        const int64_t w = base * sp;
-        return (double)w / (double)(((w + target_wgs - 1) / target_wgs) * target_wgs);
-      };
+      auto fill = [&](int64_t sp) { return grid_fill(base * sp); };
       int64_t s_max = want * 4 > want + 3 ? want * 4 : want + 3;
       if (s_max > max_by_len) s_max = max_by_len;
       if (s_max > COMBINE_MAX_SPLITS) s_max = COMBINE_MAX_SPLITS;
@@ -652,6 +656,23 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
     else
       break;
   }
+  return Shape{hgw, n_splits, grid_fill(base * n_splits)};
+  };
+  Shape sh = shape_for(hpw);
+  if (a->max_q_len <= 1 && a->n_tokens > 128 && hpw_max > 1 && forced_splits <= 0) {
+    // between 129 and ~255 tokens neither grain wins everywhere (160: wide 430 vs narrow 449 us;
+    // 192: 516 vs 504): take the one whose grid fills its last round of CUs better, then the one
+    // with fewer KV splits; a tie keeps the wide load (bs = 256: both 1 split, full rounds)
+    const Shape alt = shape_for(1);
+    if (alt.fill > sh.fill + 0.02 || (alt.fill >= sh.fill - 0.02 && alt.n_splits < sh.n_splits)) {
+      sh = alt;
+      hpw = 1;
+    }
+  }
+  pl->hpw_shift = ilog2(hpw);
+  const int nhg = a->n_kv_heads / hpw;
+  const int hgw = sh.hgw;
+  int n_splits = sh.n_splits;
   pl->hgw_shift = ilog2(hgw);
   pl->nhgb = nhg / hgw;
   pl->lds_bytes = ATTN_TBL_ENT * sizeof(int) + (size_t)hgw * state;
