@@ -725,7 +725,11 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
   // gains nothing (bs = 256: uniform 86.5 -> 91.0 us, ragged 77.8 -> 77.5 us).
   // SLM_ATTN_BAL: 0 = never, 2 = always.
   const int bal_mode = tune_get(TUNE_ATTN_BAL, 1);
-  const bool bal_pays = ((1 << pl->hpw_shift) << pl->hgw_shift) >= 4;
+  // ... and only while a workgroup's share stays long: with many KV splits (bs = 24: 16 splits, shares of
+  // ~200 tokens) the per-piece bookkeeping and the extra partials cost more than the balance gains
+  // (bs = 24 ragged 63.9 us classic vs 71.6 balanced; bs = 32, 4 splits: 80.3 vs 75.7)
+  const bool bal_pays = ((1 << pl->hpw_shift) << pl->hgw_shift) >= 4 &&
+                        a->max_kv_len / (pl->n_splits > 0 ? pl->n_splits : 1) >= 768;
   if (bal_mode != 0 && ((a->n_tokens >= 16 && bal_pays) || bal_mode == 2) && a->max_q_len <= 1 &&
       a->n_tokens == a->batch_size &&
       a->sliding_window < 0 && forced_splits <= 0 && !decode_on_tile(a) && a->n_tokens > 0) {
