@@ -288,6 +288,28 @@ def test_k_sliced_small_m_kernel_grid(bits):
         assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, knobs, err)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_seeded_fuzz_over_shapes_and_batch_sizes(seed):
+    """A seeded random walk over what the plan switches on -- M across every kernel regime (GEMV, K-sliced,
+    general POST / PRE, wave-specialised), K from one chunk to several workgroups' worth, N that is not a
+    multiple of any tile run, every group size, both formats, act-order, bias on / off, both dtypes -- each
+    case against the oracle dequant + fp32 GEMM at the reference's tolerance."""
+    rng = np.random.default_rng(1000 + seed)
+    Ms = [1, 2, 3, 4, 5, 8, 16, 31, 32, 33, 48, 64, 65, 100, 128, 129, 200, 256, 300]
+    for i in range(40):
+        M = int(rng.choice(Ms))
+        K = int(rng.integers(1, 25)) * 128
+        N = int(rng.integers(1, 25)) * 32
+        gs = int(rng.choice([-1, 32, 64, 128]))
+        fmt = str(rng.choice(["awq", "gptq"]))
+        act = fmt == "gptq" and gs not in (-1, K) and bool(rng.integers(0, 2))
+        bits = str(rng.choice(["bf16", "f16"]))
+        case = helpers.make_quant_case(5000 + 100 * seed + i, K, N, gs, fmt, bits, act_order=act)
+        out, ref = _run_gemm(case, bits, M, bias=bool(rng.integers(0, 2)), seed=i)
+        err = _rel_err(out, ref)
+        assert err < GEMM_TOL[bits], (seed, i, M, N, K, gs, fmt, act, bits, err)
+
+
 @pytest.mark.parametrize("bits", ["bf16", "f16"])
 @pytest.mark.parametrize("world,M,K,N,gs", [(2, 24, 1024, 256, 128), (4, 5, 2048, 160, 64),
                                             (8, 32, 4096, 256, 128), (2, 200, 1024, 384, 32)])
