@@ -184,3 +184,59 @@ def test_build_step_inputs_bit_exact_mixed_batches_and_graph_replay(n_seqs, B):
     torch.cuda.synchronize()
     assert int(flag.item()) == 1 and int(cached_d[0].item()) == int(nblk[0]) * B - 1
     assert torch.equal(cached_d[1:], before[1:])
+
+
+def test_step_input_builders_on_the_references_batch_test_golden():
+    """f4 pinned on the GPU: slm_build_step_inputs and slm_decode_advance on BatchTest.Basic
+    (src/engine/batch_test.cpp:28-113, tests/golden/batch_test_basic.npz) -- positions {0..8,7,15},
+    new_cache_slots {4..12,23,47}, q_cu {0,9,10,11}, kv_cu {0,9,17,33}; eager and hipGraph replay."""
+    import os
+    from scalellm_amd import kernels
+    f = np.load(os.path.join(os.path.dirname(__file__), "golden", "batch_test_basic.npz"))
+    g = {k: f[k] for k in f.files}
+    B = int(g["block_size"][0])
+    cached = g["kv_cached"].astype(np.int32)
+    q = (g["n_tokens"] - cached).astype(np.int32)
+    table = (g["seq_block_ids"] * B).astype(np.int32)
+    bcu = g["seq_block_cu"].astype(np.int32)
+    T = int(q.sum())
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(DEV)  # noqa: E731
+    for pad in (0, 5):
+        q_d, cached_d, table_d, bcu_d = dev(q), dev(cached), dev(table), dev(bcu)
+        pos_d = torch.full((T + pad,), -7, dtype=torch.int32, device=DEV)
+        slots_d = torch.full((T + pad,), -7, dtype=torch.int32, device=DEV)
+        qcu_d = torch.full((len(q) + 1,), -7, dtype=torch.int32, device=DEV)
+        kcu_d = torch.full((len(q) + 1,), -7, dtype=torch.int32, device=DEV)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        if pad == 0:
+            kernels.build_step_inputs(q_d, cached_d, table_d, bcu_d, B, pos_d, qcu_d, kcu_d, slots_d,
+                                      commit=True, overflow_flag=flag)
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                kernels.build_step_inputs(q_d, cached_d, table_d, bcu_d, B, pos_d, qcu_d, kcu_d, slots_d,
+                                          commit=True, overflow_flag=flag)
+            cached_d.copy_(dev(cached))
+            graph.replay()
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 0
+        np.testing.assert_array_equal(pos_d.cpu().numpy()[:T], g["expected_pos"])
+        np.testing.assert_array_equal(slots_d.cpu().numpy()[:T], g["new_cache_slots"])
+        np.testing.assert_array_equal(qcu_d.cpu().numpy(), g["q_cu_seq_lens"])
+        np.testing.assert_array_equal(kcu_d.cpu().numpy(), g["kv_cu_seq_lens"])
+        assert not pos_d.cpu().numpy()[T:].any() and not slots_d.cpu().numpy()[T:].any()
+        np.testing.assert_array_equal(cached_d.cpu().numpy(), g["kv_cached_after"])
+    # the two decode rows through slm_decode_advance from the previous step's inputs
+    dec = [1, 2]
+    d_bcu = np.concatenate([[0], np.cumsum(np.diff(bcu)[dec])]).astype(np.int32)
+    d_table = np.concatenate([table[bcu[i]:bcu[i + 1]] for i in dec])
+    pos_d = dev(cached[dec] - 1)
+    kcu_d = dev(np.concatenate([[0], np.cumsum(cached[dec])]))
+    slots_d = torch.zeros(2, dtype=torch.int32, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    kernels.decode_advance(pos_d, kcu_d, slots_d, dev(d_table), dev(d_bcu), B, flag)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(pos_d.cpu().numpy(), g["expected_pos"][-2:])
+    np.testing.assert_array_equal(slots_d.cpu().numpy(), g["new_cache_slots"][-2:])
+    np.testing.assert_array_equal(np.diff(kcu_d.cpu().numpy()), np.diff(g["kv_cu_seq_lens"])[dec])
+    assert int(flag.item()) == 0

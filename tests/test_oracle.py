@@ -190,6 +190,68 @@ def test_4bit_entry_points_agree_with_the_generic_ones():
                                           oracle.gptq_dequant(c["qweight"], c["qzeros"], sc, gs, g_idx))
 
 
+def _batch_test_basic():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "batch_test_basic.npz"))
+    return {k: g[k] for k in g.files}
+
+
+def test_step_input_builders_on_the_references_own_golden():
+    """f4 PINNED: BatchTest.Basic (src/engine/batch_test.cpp:28-113) -- the reference's known-answer
+    vectors for Batch::prepare_model_input (one 9-token prefill + two decode sequences, block size 4,
+    blocks [1,2,3 | 4..7 | 8..12]) -- fed to the oracle functions the GPU builders are checked against:
+    `oracle.build_step_inputs` (all tensors of the step), `oracle.decode_advance` (the two decode rows
+    reached from the PREVIOUS step's inputs), `oracle.all_slots` (block table -> slot of every cached
+    position).  Vectors come from tests/golden/make_golden.py::make_batch_test (parsed from the source)."""
+    g = _batch_test_basic()
+    B = int(g["block_size"][0])
+    n_tokens, cached = g["n_tokens"], g["kv_cached"]
+    q = n_tokens - cached                                            # tokens not yet in the cache (batch.cpp:120-131)
+    table = (g["seq_block_ids"] * B).astype(np.int32)                # block.id * block.size (batch.cpp:206-209)
+    bcu = g["seq_block_cu"]
+    np.testing.assert_array_equal(table, g["block_id_tables"] * B)   # EXPECT(block_tables == ids * block_size)
+    np.testing.assert_array_equal(bcu, g["cu_block_lens"])
+    T = int(q.sum())
+    for pad in (0, 5):
+        pos, qcu, kcu, slots, missing = oracle.build_step_inputs(q, cached, table, bcu, B, T + pad)
+        assert missing == 0
+        np.testing.assert_array_equal(pos[:T], g["expected_pos"])
+        np.testing.assert_array_equal(slots[:T], g["new_cache_slots"])
+        np.testing.assert_array_equal(qcu, g["q_cu_seq_lens"])
+        np.testing.assert_array_equal(kcu, g["kv_cu_seq_lens"])
+        assert not pos[T:].any() and not slots[T:].any()
+    assert int(np.diff(qcu).max()) == int(g["q_max_seq_len"][0])
+    assert int(np.diff(kcu).max()) == int(g["kv_max_seq_len"][0])
+    assert len(q) == int(g["num_sequences"][0])
+    np.testing.assert_array_equal(cached + q, g["kv_cached_after"])  # num_kv_cache_tokens after the step
+    # the flattened token ids are the not-yet-cached tail of every sequence (batch.cpp:149-156)
+    tcu = np.concatenate([[0], np.cumsum(n_tokens)])
+    toks = np.concatenate([g["token_ids_in"][tcu[i] + cached[i]:tcu[i + 1]] for i in range(len(q))])
+    np.testing.assert_array_equal(toks, g["expected_tokens"])
+    # decode_advance: the two decode sequences (seq2, seq3) one step earlier had positions 6 / 14
+    dec = [1, 2]
+    d_bcu = np.concatenate([[0], np.cumsum(np.diff(bcu)[dec])]).astype(np.int32)
+    d_table = np.concatenate([table[bcu[i]:bcu[i + 1]] for i in dec])
+    prev_pos = (cached[dec] - 1).astype(np.int32)
+    prev_kcu = np.concatenate([[0], np.cumsum(cached[dec])]).astype(np.int32)
+    pos2, kcu2, slots2, missing = oracle.decode_advance(prev_pos, prev_kcu, d_table, d_bcu, B)
+    assert missing == 0
+    np.testing.assert_array_equal(pos2, g["expected_pos"][-2:])          # {7, 15}
+    np.testing.assert_array_equal(slots2, g["new_cache_slots"][-2:])     # {23, 47}
+    np.testing.assert_array_equal(np.diff(kcu2), np.diff(g["kv_cu_seq_lens"])[dec])   # {8, 16}
+    # slot of every position the attention kernel will read == block id * B + offset, and the new
+    # tokens' slots are its tail per sequence
+    alls = oracle.all_slots(table, bcu, g["kv_cu_seq_lens"], B)
+    off = 0
+    for i in range(len(q)):
+        L = int(cached[i] + q[i])
+        exp = [int(g["seq_block_ids"][bcu[i] + j // B]) * B + j % B for j in range(L)]
+        np.testing.assert_array_equal(alls[off:off + L], exp)
+        off += L
+    new_tail = np.concatenate([alls[g["kv_cu_seq_lens"][i + 1] - q[i]:g["kv_cu_seq_lens"][i + 1]] for i in range(len(q))])
+    np.testing.assert_array_equal(new_tail, g["new_cache_slots"])
+
+
 def _ref_prepare_model_input(seqs, B):
     """Batch::prepare_model_input (engine/batch.cpp:97-255) restated line by line on Python lists:
     seqs = [(n_kv_cache_tokens, q_seq_len, [block ids])]; returns the integer tensors it builds."""
