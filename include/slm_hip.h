@@ -100,7 +100,10 @@ typedef struct slm_attn_args {
   int32_t head_dim;         /* multiple of 8, <= 256                          */
   int32_t block_size;       /* power of two (mha_params.h:71-74)              */
   int32_t max_q_len;        /* scheduling hint, as in the reference           */
-  int32_t max_kv_len;       /* scheduling hint (unused by the reference)      */
+  int32_t max_kv_len;       /* scheduling hint (unused by the reference): sizes the KV splits /
+                             * the balanced decode partition.  Results are correct for ANY value:
+                             * a sequence longer than the hint is streamed by one workgroup
+                             * (slower, never wrong or out of bounds)                          */
   float sm_scale;
   float logits_soft_cap;    /* 0 = off                                        */
   int32_t sliding_window;   /* -1 = off                                       */
@@ -396,7 +399,9 @@ SLM_API int slm_decode_advance(int32_t* positions /* [n_seqs] */, int32_t* kv_cu
  *     commit != 0: kv_cached[b] += q afterwards         (Sequence::commit_kv_cache, batch.cpp:197)
  * Rows t in [q_cu_lens[n_seqs], n_tokens_padded) are the graph padding of batch.cpp:219-244:
  * position 0, slot 0.  A position without a block sets *overflow_flag |= 1 and is clamped to the
- * sequence's last block (the host then discards the step).  A sequence with q = 0 (no token budget
+ * sequence's last block (slot 0 when the sequence has no block at all; the host then discards the
+ * step).  More new tokens than n_tokens_padded rows sets *overflow_flag |= 2: the rows that fit are
+ * written, the cache positions are NOT committed.  A sequence with q = 0 (no token budget
  * this step: the reference drops it from the batch, batch.cpp:113-117) stays in the arrays as an
  * empty row range; the attention kernels skip it.  The host keeps what only it can decide: which
  * sequences run, their token budgets (q_lens), block allocation (appending first-slot ids).

@@ -87,8 +87,15 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
   // Balanced pure-decode partition (p.bal; plan_attn): this workgroup is number w of its head
   // group and owns the tokens [g, g1) of the concatenated histories; it walks the sequences that
   // range touches ("pieces"), each piece a complete pass of the body below with its own partial.
+  // The plan enables it from host hints (max_q_len <= 1, n_tokens == batch_size); the kernel
+  // re-checks the one thing it relies on -- token index == sequence index -- on the device: with
+  // every q_len <= 1 (max_q_len is the grid contract, tile_scheduler.cuh:23-27) q_cu[batch] == batch
+  // means q_cu[i] == i.  A batch that keeps q = 0 sequences next to graph-padding rows
+  // (slm_build_step_inputs allows it) fails the check and runs the classic partition, which follows
+  // q_cu (same grid; part_slots > n_splits, so the partial slots are there).
+  const bool bal = p.bal && p.q_cu[p.batch] == p.batch;
   int bal_g = 0, bal_g1 = 0, bal_Q = 1;  // (all < 2^31: kv_cu is int32)
-  if (p.bal) {
+  if (bal) {
     const int W = p.kv_cu[p.batch];
     bal_Q = attn_bal_q(p, W);
     const int64_t g64 = (int64_t)(tok * p.n_splits + split) * bal_Q;
@@ -103,7 +110,7 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
     b = lo_b;
   }
   if (b >= p.batch) return;  // padding token past q_cu[batch]
-  if (!p.bal) {
+  if (!bal) {
     const int rows = (p.q_cu[b + 1] - p.q_cu[b]) * p.group;
     if (rows < p.rows_lo || rows >= p.rows_hi) return;  // another launch owns this sequence
   }
@@ -137,14 +144,29 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
   for (;;) {  // one pass per piece (classic partition: exactly one)
   int tok_p = tok, s_lo, s_hi, part_idx = split;
   bool single = p.n_splits == 1;  // the pass covers its sequence alone: it writes the final output
-  if (p.bal) {
+  bool skip = false;
+  if (bal) {
     const int kv0 = p.kv_cu[b], kv1 = p.kv_cu[b + 1];
     tok_p = b;  // pure decode: token index == sequence index
     s_lo = bal_g - kv0;
     s_hi = min(kv1, bal_g1) - kv0;
     const int w_first = kv0 / bal_Q;
+    const int n_pc = (kv1 - 1) / bal_Q - w_first + 1;  // pieces of this sequence
     part_idx = bal_g / bal_Q - w_first;
-    single = (kv1 - 1) / bal_Q == w_first;
+    single = n_pc == 1;
+    if (n_pc > p.part_slots) {
+      // longer than the max_kv_len hint promised (bal_qmin is derived from it): more pieces than
+      // partial slots.  max_kv_len stays a HINT: the workgroup that holds the first piece streams
+      // the whole sequence and writes the final row, the others skip it (correct for any hint,
+      // unbalanced for that sequence); the combine kernel takes the same decision.
+      if (part_idx == 0) {
+        s_hi = kv1 - kv0;
+        single = true;
+      } else {
+        skip = true;
+        s_hi = s_lo;
+      }
+    }
   } else {
     const int q_start = p.q_cu[b];
     const int q_len = p.q_cu[b + 1] - q_start;
@@ -383,7 +405,7 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
     }
   }
 
-  if (rp == 0 && rsub == 0 && act) {
+  if (rp == 0 && rsub == 0 && act && !skip) {
     // (opaque copy: keeps hipcc from hoisting the GC output addresses out of the piece loop, where
     // they would sit in -- or spill from -- registers across the whole stream)
     int qh0 = qh0_lane;
@@ -415,7 +437,7 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
       }
     }
   }
-  if (!p.bal) break;
+  if (!bal) break;
   // next piece: the following non-empty sequence, if this workgroup's range reaches into it
   do {
     ++b;
@@ -459,7 +481,9 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const AttnKParams p, 
     if (rows < p.rows_lo || rows >= p.rows_hi) return;
   }
   int n_used = p.n_splits;
-  if (p.bal) {
+  const bool bal = p.bal && q_end == p.batch;  // the stream kernel's device-side check (attn_token_kernel)
+  if (p.bal && !bal && p.n_splits == 1) return;  // classic fallback, one split: final rows already written
+  if (bal) {
     // balanced pure-decode partition: the pieces of sequence tok come from the consecutive
     // workgroups floor(kv_cu[tok] / Q) .. floor((kv_cu[tok + 1] - 1) / Q) (attn_common.h)
     if (!valid || tok >= p.batch) return;
@@ -473,7 +497,9 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const AttnKParams p, 
     }
     const int Q = attn_bal_q(p, p.kv_cu[p.batch]);
     n_used = (kv1 - 1) / Q - kv0 / Q + 1;
-    if (n_used == 1) return;  // the one piece wrote the final output itself
+    // one piece, or more pieces than slots (a sequence past the max_kv_len hint: streamed whole by
+    // the workgroup of its first piece): the final output is already written
+    if (n_used == 1 || n_used > p.part_slots) return;
   }
   const float* ml = p.ml_part + item * p.part_slots * 2;
   // every load below is UNCONDITIONAL (index clamped, result masked afterwards): a load inside a

@@ -125,6 +125,10 @@ __global__ void __launch_bounds__(BSI_THREADS) build_step_inputs_kernel(
     __syncthreads();
   }
   const int32_t n_tok = carry[0];
+  // more new tokens than rows: the tail would be dropped while q_cu / kv_cu (and the commit) count
+  // it -- flag bit 1 (value 2) and do NOT advance the cache positions over tokens nobody appends
+  const bool too_many = n_tok > n_tokens_padded;
+  if (too_many && tid == 0 && overflow_flag) atomicOr(overflow_flag, 2);
   // ---- fill: token t belongs to the sequence b with q_cu[b] <= t < q_cu[b + 1] (this workgroup's own
   // writes: visible after the barriers above)
   for (int32_t t = tid; t < n_tokens_padded; t += BSI_THREADS) {
@@ -145,12 +149,13 @@ __global__ void __launch_bounds__(BSI_THREADS) build_step_inputs_kernel(
     int32_t blk = j >> shift;
     if (blk >= nblk) {  // the host has not appended the block yet
       if (overflow_flag) atomicOr(overflow_flag, 1);
-      blk = nblk > 0 ? nblk - 1 : 0;
+      blk = nblk - 1;
     }
     positions[t] = j;
-    new_cache_slots[t] = block_table[bbase + blk] + (j & mask);  // sequence.cpp:303-317
+    // (a sequence without any block: slot 0, its table range is empty -- nothing of it is read)
+    new_cache_slots[t] = blk >= 0 ? block_table[bbase + blk] + (j & mask) : 0;  // sequence.cpp:303-317
   }
-  if (commit) {  // Sequence::commit_kv_cache (batch.cpp:197): after every read of kv_cached above
+  if (commit && !too_many) {  // Sequence::commit_kv_cache (batch.cpp:197): after every read of kv_cached above
     __syncthreads();
     for (int32_t b = tid; b < n_seqs; b += BSI_THREADS) {
       const int32_t q = q_lens[b];

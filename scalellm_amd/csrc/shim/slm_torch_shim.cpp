@@ -256,6 +256,28 @@ struct SzEntry {
 std::mutex g_sz_mu;
 std::unordered_map<SzKey, SzEntry, SzKeyHash> g_sz_cache;
 
+// num_bits = 8: the doubled activation gather perm2[k'] = perm[k' mod K] (or k' mod K), one per
+// (perm tensor, K, device), same lifetime rule as the sz tables
+struct Perm2Key {
+  const void* perm;
+  uint32_t version;
+  int64_t K;
+  int device;
+  bool operator==(const Perm2Key& o) const {
+    return perm == o.perm && version == o.version && K == o.K && device == o.device;
+  }
+};
+struct Perm2KeyHash {
+  size_t operator()(const Perm2Key& k) const {
+    return std::hash<const void*>()(k.perm) ^ std::hash<int64_t>()(k.K * 131 + k.version * 7 + k.device);
+  }
+};
+struct Perm2Entry {
+  torch::Tensor perm2;
+  c10::weak_intrusive_ptr<c10::StorageImpl> perm_st;
+};
+std::unordered_map<Perm2Key, Perm2Entry, Perm2KeyHash> g_perm2_cache;
+
 bool same_live_storage(const c10::weak_intrusive_ptr<c10::StorageImpl>& w, const torch::Tensor& t) {
   const auto alive = w.lock();
   return alive && alive.get() == t.storage().unsafeGetStorageImpl();
@@ -412,9 +434,29 @@ void gptq_gemm(const torch::Tensor& A, const torch::Tensor& B, torch::Tensor& C,
   const bool has_perm = perm.defined() && perm.numel() > 0;
   torch::Tensor perm2;  // 8 bits: packed row k' reads activation column perm[k' mod K]
   if (w8) {
-    const auto base = has_perm ? perm.to(torch::kInt)
-                               : torch::arange(K, torch::dtype(torch::kInt).device(A.device()));
-    perm2 = torch::cat({base, base}).contiguous();
+    // built once per (perm tensor, K) and kept next to the sz tables: no allocation and no extra
+    // launches on the decode path (and none inside a stream capture after the warm-up call)
+    const auto ver = [](const torch::Tensor& t) { return t.is_inference() ? 0u : t._version(); };
+    const Perm2Key pk{has_perm ? perm.const_data_ptr() : nullptr, has_perm ? ver(perm) : 0u, K,
+                      static_cast<int>(A.device().index())};
+    std::lock_guard<std::mutex> lk(g_sz_mu);
+    auto it = g_perm2_cache.find(pk);
+    if (it != g_perm2_cache.end() && has_perm && !same_live_storage(it->second.perm_st, perm)) {
+      g_perm2_cache.erase(it);
+      it = g_perm2_cache.end();
+    }
+    if (it == g_perm2_cache.end()) {
+      for (auto e = g_perm2_cache.begin(); e != g_perm2_cache.end();)
+        e = (e->first.perm && e->second.perm_st.expired()) ? g_perm2_cache.erase(e) : std::next(e);
+      const auto base = has_perm ? perm.to(torch::kInt)
+                                 : torch::arange(K, torch::dtype(torch::kInt).device(A.device()));
+      perm2 = torch::cat({base, base}).contiguous();
+      using WeakStorage = c10::weak_intrusive_ptr<c10::StorageImpl>;
+      g_perm2_cache.emplace(pk, Perm2Entry{perm2, has_perm ? WeakStorage(perm.storage().getWeakStorageImpl())
+                                                            : WeakStorage(perm2.storage().getWeakStorageImpl())});
+    } else {
+      perm2 = it->second.perm2;
+    }
   }
   slm_w4_gemm_args g{};
   g.a = A.const_data_ptr();
@@ -594,13 +636,22 @@ torch::Tensor W4Linear::forward(const torch::Tensor& input, const std::optional<
 }
 
 torch::Tensor W4Linear::dequantize() const {
+  // The dense weight of the CHECKPOINT, [in_features, N] in its own row order, whatever the packing:
+  // the packed rows k' (act-order: sorted by group; 8 bits: two int4 planes over 2K rows; padded
+  // act-order shards: perm = -1 rows that hold nothing) are dequantised as the kernels see them and
+  // scattered back, W[perm[k']] += Wp[k'] in fp32, rounded to T once.
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(wq_.device());
-  auto w = torch::empty({K_, N_}, torch::dtype(dtype_).device(wq_.device()));
+  auto wp = torch::empty({K_, N_}, torch::dtype(dtype_).device(wq_.device()));
   check(slm_w4_dequant(wq_.const_data_ptr(), sz_.const_data_ptr(), K_, N_, group_size_,
-                       dtype_ == torch::kBFloat16 ? SLM_BF16 : SLM_F16, w.mutable_data_ptr(),
+                       dtype_ == torch::kBFloat16 ? SLM_BF16 : SLM_F16, wp.mutable_data_ptr(),
                        current_stream(wq_)),
         "slm_w4_dequant");
-  return w;
+  if (!perm_.defined()) return wp;
+  const auto idx = perm_.to(torch::kLong);
+  const auto live = idx.ge(0);
+  auto w = torch::zeros({k_src_, N_}, torch::dtype(torch::kFloat).device(wq_.device()));
+  w.index_add_(0, idx.masked_select(live), wp.to(torch::kFloat).index({live}));
+  return w.to(dtype_);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -240,3 +240,49 @@ def test_step_input_builders_on_the_references_batch_test_golden():
     np.testing.assert_array_equal(slots_d.cpu().numpy(), g["new_cache_slots"][-2:])
     np.testing.assert_array_equal(np.diff(kcu_d.cpu().numpy()), np.diff(g["kv_cu_seq_lens"])[dec])
     assert int(flag.item()) == 0
+
+
+def test_build_step_inputs_flags_more_tokens_than_rows_and_blockless_sequences():
+    """(a) sum(q_lens) > n_tokens_padded -- the rows that fit are written, flag bit 1
+    (value 2) is raised and the cache positions are NOT committed (they would advance over tokens
+    nobody appends); (b) a sequence with no block at all gets slot 0 and flag bit 0 without the
+    kernel reading the next sequence's table entry."""
+    from scalellm_amd import kernels
+    B = 16
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(DEV)  # noqa: E731
+    q = np.asarray([5, 3, 4], np.int32)
+    cached = np.asarray([0, 16, 2], np.int32)
+    table = np.asarray([32, 64, 80, 96], np.int32)
+    bcu = np.asarray([0, 1, 3, 4], np.int32)
+    T_pad = 8                                   # 12 tokens asked for
+    q_d, cached_d = dev(q), dev(cached)
+    pos_d = torch.full((T_pad,), -7, dtype=torch.int32, device=DEV)
+    slots_d = torch.full((T_pad,), -7, dtype=torch.int32, device=DEV)
+    qcu_d = torch.zeros(4, dtype=torch.int32, device=DEV)
+    kcu_d = torch.zeros(4, dtype=torch.int32, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    kernels.build_step_inputs(q_d, cached_d, dev(table), dev(bcu), B, pos_d, qcu_d, kcu_d, slots_d, commit=True,
+                              overflow_flag=flag)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 2
+    np.testing.assert_array_equal(cached_d.cpu().numpy(), cached)          # not committed
+    pos, qcu, kcu, slots, _ = oracle.build_step_inputs(q, cached, table, bcu, B, T_pad)
+    np.testing.assert_array_equal(pos_d.cpu().numpy(), pos)
+    np.testing.assert_array_equal(slots_d.cpu().numpy(), slots)
+    np.testing.assert_array_equal(qcu_d.cpu().numpy(), qcu)
+    # (b) the LAST sequence has no block: its table range is empty and ends the table
+    q = np.asarray([1, 2], np.int32)
+    cached = np.asarray([3, 0], np.int32)
+    table = np.asarray([48], np.int32)
+    bcu = np.asarray([0, 1, 1], np.int32)
+    pos_d = torch.full((4,), -7, dtype=torch.int32, device=DEV)
+    slots_d = torch.full((4,), -7, dtype=torch.int32, device=DEV)
+    qcu_d = torch.zeros(3, dtype=torch.int32, device=DEV)
+    kcu_d = torch.zeros(3, dtype=torch.int32, device=DEV)
+    flag.zero_()
+    kernels.build_step_inputs(dev(q), dev(cached), dev(table), dev(bcu), B, pos_d, qcu_d, kcu_d, slots_d,
+                              commit=False, overflow_flag=flag)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
+    np.testing.assert_array_equal(pos_d.cpu().numpy(), [3, 0, 1, 0])
+    np.testing.assert_array_equal(slots_d.cpu().numpy(), [48 + 3, 0, 0, 0])

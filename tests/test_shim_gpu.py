@@ -102,6 +102,12 @@ def test_shim_w4linear(shim, fmt):
     ref = oracle.gemm_f32(a.float().cpu().numpy(), w) + bias.float().cpu().numpy()[None]
     out = c.float().cpu().numpy()
     assert np.abs(out - ref).mean() / np.abs(ref).mean() < 8e-3
+    # dequantize(): the checkpoint's dense [in_features, N] in ITS row order (act-order rows are
+    # scattered back), each value = T(s (q - z)) exactly
+    wd = lin.dequantize()
+    assert tuple(wd.shape) == (lin.in_features(), lin.out_features())
+    w_t = torch.from_numpy(w).to(torch.bfloat16).float().numpy()
+    np.testing.assert_array_equal(wd.float().cpu().numpy(), w_t)
 
 
 @pytest.mark.parametrize("fmt,act", [("awq", False), ("gptq", False), ("gptq", True)])
@@ -126,6 +132,13 @@ def test_shim_w4linear_8bit(shim, fmt, act):
     assert torch.equal(c, c_py)
     ref = oracle.gemm_f32(a.float().cpu().numpy(), helpers.dense_weight8(case)) + bias.float().cpu().numpy()[None]
     assert np.abs(c.float().cpu().numpy() - ref).mean() / np.abs(ref).mean() < 8e-3
+    # dequantize() of an 8-bit layer: hi plane + lo plane summed back to [K, N] (it used to
+    # return the two stacked planes [2K, N]); each plane is rounded to T, then their fp32 sum once more
+    wd = lin.dequantize()
+    assert tuple(wd.shape) == (512, 256)
+    w8 = helpers.dense_weight8(case)
+    err = np.abs(wd.float().cpu().numpy() - w8)
+    assert err.max() <= 2.0 ** -7 * np.abs(w8).max() and err.mean() / np.abs(w8).mean() < 4e-3
 
 
 def test_shim_process_group_rccl_single_gpu(shim):
