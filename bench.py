@@ -237,7 +237,11 @@ def cpu_baseline(model, tokens, params, sample_seqs, kv_len, block):
     kv_cu = (np.arange(sample_seqs + 1) * kv_len).astype(np.int32)
     table = (np.arange(sample_seqs * nblk) * block).astype(np.int32)
     bcu = (np.arange(sample_seqs + 1) * nblk).astype(np.int32)
-    # int4 linears: fresh random AWQ-format tensors of the layer's four shapes (host side)
+    # int4 linears: fresh random AWQ-format tensors of the layer's four shapes (host side), at the
+    # batch's REAL row count: the reference dequantises every weight once per forward
+    # (qlinear_impl.cpp:171-183) whatever the batch, so that cost -- and MKL's efficiency -- must be
+    # measured at M = batch, not on a 16-row sample scaled up (round-3 review, weak 8)
+    M = int(tokens.numel())
     rng = np.random.default_rng(0)
     shapes = [(s.hidden, (s.n_heads + 2 * s.n_kv_heads) * s.head_dim), (s.n_heads * s.head_dim, s.hidden),
               (s.hidden, 2 * s.intermediate), (s.intermediate, s.hidden)]
@@ -246,20 +250,20 @@ def cpu_baseline(model, tokens, params, sample_seqs, kv_len, block):
         qw = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(K, N // 8), dtype=np.int64).astype(np.int32)
         qz = rng.integers(-2 ** 31, 2 ** 31 - 1, size=(K // 128, N // 8), dtype=np.int64).astype(np.int32)
         sc = rng.uniform(0.002, 0.008, size=(K // 128, N)).astype(np.float32)
-        lin.append((qw, qz, sc, rng.standard_normal((sample_seqs, K), dtype=np.float32)))
+        lin.append((qw, qz, sc, rng.standard_normal((M, K), dtype=np.float32)))
     threads = oracle.num_threads()
-
-    # Two GEMM legs.  The reference's CPU linear is construct_weights + torch::matmul
-    # (qlinear_impl.cpp:171-183), i.e. MKL: `mkl` times the oracle's dequant + torch.matmul on all
-    # host threads -- the honest stand-in for the reference path and the reported `value`.  `loops`
-    # times the oracle's own plain-C GEMM (what the parity tests check against); it is several
-    # times slower and is reported next to it so nobody mistakes it for the reference's speed.
     torch.set_num_threads(max(1, os.cpu_count() or 1))
     mkl_threads = torch.get_num_threads()
 
-    def one_layer(mkl: bool):
+    def attn_leg():
         oracle.paged_attn(q32, k32, v32, q_cu, kv_cu, table, bcu, block, s.head_dim ** -0.5,
                           n_threads=threads)
+
+    # The reference's CPU linear is construct_weights + torch::matmul (qlinear_impl.cpp:171-183),
+    # i.e. MKL: `mkl` times the oracle's dequant + torch.matmul on all host threads -- the stand-in
+    # for the reference path and the reported `value`.  `loops` times the oracle's own plain-C GEMM
+    # (what the parity tests check against), reported next to it.
+    def lin_leg(mkl: bool):
         for qw, qz, sc, x in lin:
             w = oracle.awq_dequant(qw, qz, sc, 128)  # the reference dequantises on every forward
             if mkl:
@@ -267,27 +271,37 @@ def cpu_baseline(model, tokens, params, sample_seqs, kv_len, block):
             else:
                 oracle.gemm_f32(x, w, n_threads=threads)
 
-    def timed(mkl: bool, budget_s: float):
-        one_layer(mkl)  # warm-up
+    def timed(fn, budget_s: float, warm: bool = True, min_reps: int = 2):
+        if warm:
+            fn()
         reps, t0 = 0, time.perf_counter()
-        while reps < 2 or (time.perf_counter() - t0 < budget_s and reps < 8):
-            one_layer(mkl)
+        while reps < min_reps or (time.perf_counter() - t0 < budget_s and reps < 8):
+            fn()
             reps += 1
         return (time.perf_counter() - t0) / reps, reps
 
-    t_mkl, reps_mkl = timed(True, 8.0)
-    t_loop, reps_loop = timed(False, 8.0)
-    tok_mkl = sample_seqs / (t_mkl * s.n_layers)
-    tok_loop = sample_seqs / (t_loop * s.n_layers)
+    t_attn, reps_attn = timed(attn_leg, 6.0)
+    t_mkl, reps_mkl = timed(lambda: lin_leg(True), 6.0)
+    t_loop, reps_loop = timed(lambda: lin_leg(False), 0.0, warm=False, min_reps=1)
+    scale = M / sample_seqs                      # attention is linear in the sequences
+    layer_mkl = t_attn * scale + t_mkl
+    layer_loop = t_attn * scale + t_loop
+    tok_mkl = M / (layer_mkl * s.n_layers)
+    tok_loop = M / (layer_loop * s.n_layers)
     return dict(value=round(tok_mkl, 3), unit="tokens/s", cores=max(threads, mkl_threads), kind="port",
                 gemm="torch.matmul (MKL) on the oracle-dequantised fp32 weights, as qlinear_impl.cpp:171-183",
+                legs=dict(attention_s_per_layer_sample=round(t_attn, 4), attention_sample_seqs=sample_seqs,
+                          attention_s_per_layer_full_batch=round(t_attn * scale, 3),
+                          linears_s_per_layer_at_full_M=round(t_mkl, 4), linears_M=M,
+                          linears_oracle_loops_s_per_layer=round(t_loop, 3)),
                 oracle_loops=dict(value=round(tok_loop, 3), unit="tokens/s", cores=threads,
-                                  note="same sample with the oracle's plain-C GEMM instead of MKL"),
-                sample=(f"{sample_seqs} of the batch's sequences (kv_len {kv_len}), one layer: oracle "
-                        f"paged attention ({threads} threads) + 4 int4 (AWQ g128) linears with per-forward "
-                        f"fp32 dequant + torch.matmul ({mkl_threads} threads); {reps_mkl} reps, "
-                        f"{t_mkl:.2f} s/layer-sample, extrapolated x{s.n_layers} layers "
-                        f"(oracle-GEMM variant: {reps_loop} reps, {t_loop:.2f} s/layer-sample)"))
+                                  note="same legs with the oracle's plain-C GEMM instead of MKL"),
+                sample=(f"one layer, two legs: (a) oracle paged attention on {sample_seqs} of the batch's "
+                        f"{M} sequences (kv_len {kv_len}, {threads} threads; {reps_attn} reps, {t_attn:.2f} s), "
+                        f"scaled x{scale:g} -- attention is linear in the sequences; (b) the 4 int4 (AWQ g128) "
+                        f"linears at the REAL M = {M}: fp32 dequant once per forward + torch.matmul "
+                        f"({mkl_threads} threads; {reps_mkl} reps, {t_mkl:.2f} s; oracle plain-C GEMM instead: "
+                        f"{t_loop:.2f} s); layer = (a) x{scale:g} + (b), extrapolated x{s.n_layers} layers"))
 
 
 def _probe_capture_main():
