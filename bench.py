@@ -460,6 +460,8 @@ def main():
     ap.add_argument("--advance", action="store_true", help="include the device-side input build "
                     "(slm_decode_advance, SURVEY 8f f4) in the step: every replay appends one token "
                     "per sequence, so kv_len grows by one per step from --seqlen")
+    ap.add_argument("--lanes", type=int, default=-1, help="two half-batch lanes on two streams for pure-decode "
+                    "batches of >= N tokens (0 = never; default: SLM_DECODE_LANES or the library's auto policy)")
     ap.add_argument("--simulate-tp", type=int, default=0, help="tuning aid: run rank 0's shard of a "
                     "TP=N step on one GPU with the collectives stubbed (flagged in the output)")
     args = ap.parse_args()
@@ -511,6 +513,8 @@ def main():
     model = LlamaDecodeStep(shape, bs, n_blocks, B, pa, quant_method=quant, group_size=128,
                             dtype=torch.bfloat16, device=device, seed=0, kv_fill=args.kv_fill,
                             custom_allreduce=custom_ar, gptq_sym=gptq_sym, bits=args.bits)
+    if args.lanes >= 0:
+        model.lanes_min = args.lanes
     model.reserve_workspaces(bs, L)
     torch.cuda.synchronize()
     t_init = time.perf_counter() - t_init
@@ -605,8 +609,13 @@ def main():
     tok_s = bs * args.steps / elapsed
 
     # ---- roofline of the dominant kernel (paged-attention decode), this rank's shard ----
-    avg_us, med_us = measure_attention_kernel(model, tokens, positions, params, n_launch=32)
-    nbytes = attn_algo_bytes(bs, L, model.n_heads, model.n_kv_heads, shape.head_dim, B)
+    # (two-lane steps launch the attention once per HALF batch: that launch is the one measured)
+    attn_rows, attn_params = bs, params
+    if model.last_lanes == 2:
+        lane0 = model._make_lanes(bs, positions, params, model.buf["o"][:bs], model.buf["down"][:bs], None, False)[0]
+        attn_rows, attn_params = lane0.T, lane0.params
+    avg_us, med_us = measure_attention_kernel(model, tokens[:attn_rows], positions, attn_params, n_launch=32)
+    nbytes = attn_algo_bytes(attn_rows, L, model.n_heads, model.n_kv_heads, shape.head_dim, B)
     achieved = nbytes / avg_us / 1e3  # GB/s
     # HBM traffic of that launch from the PMC counters, measured IN THIS RUN (rank 0, N = 1): two
     # rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) over a child process
@@ -614,17 +623,19 @@ def main():
     gemm = measure_gemm(model, bs)  # (before the profiler children below: same clocks as the timed steps)
     traffic, traffic_src = (None, None)
     if rank == 0 and world == 1 and not args.no_traffic:
-        traffic, traffic_src = measure_attention_traffic_live(bs, L, model.n_heads, model.n_kv_heads, B)
+        traffic, traffic_src = measure_attention_traffic_live(attn_rows, L, model.n_heads, model.n_kv_heads, B)
     # which kernel ran the q_len = 1 rows: asked of the library's own plan (tuning knobs included),
     # not re-derived here -- the MFMA tile kernel for wide GQA groups, the token-major stream otherwise
     on_tile = kernels.paged_kv_varlen_mha_decode_kernel(
-        bs, bs, model.n_heads, model.n_kv_heads, shape.head_dim, B, 1, L, model.dtype) == "attn_tile_kernel"
+        attn_rows, attn_rows, model.n_heads, model.n_kv_heads, shape.head_dim, B, 1, L, model.dtype) == "attn_tile_kernel"
     roofline = dict(kernel="attn_tile_kernel (paged-attention decode, MFMA tile form)" if on_tile
                     else "attn_token_kernel (paged-attention decode)", bound="hbm",
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_src,
                     algorithmic_bytes_per_launch=nbytes, avg_launch_us=round(avg_us, 2),
-                    median_launch_us=round(med_us, 2), launches="5 x 32 (hipGraph replay)")
+                    median_launch_us=round(med_us, 2), launches="5 x 32 (hipGraph replay)",
+                    sequences_per_launch=attn_rows,
+                    launches_per_layer=model.last_lanes)
 
     out = None
     if rank == 0:
@@ -648,7 +659,7 @@ def main():
                        "model": args.model,
                        "global_batch": bs, "seq_len": L,
                        "parallelism": f"tp{world}" if world > 1 else "single-gpu",
-                       "hip_graph": graph is not None, "reduced_model": reduced,
+                       "hip_graph": graph is not None, "decode_lanes": model.last_lanes, "reduced_model": reduced,
                        "row_parallel_reduce": (None if world == 1 else
                                                "xgmi two-shot all-reduce fused with residual+rmsnorm "
                                                "(embedding gather and greedy sampling exchange through "

@@ -12,6 +12,7 @@ The step is hipGraph-capturable: static buffers, no host sync, no allocation aft
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 from dataclasses import dataclass
@@ -131,6 +132,16 @@ class LlamaDecodeStep:
         # GEMV's prologue (kernels.NormPrologue) -- two launches less per layer where the step is
         # launch-bound.  Identical bits either way.
         self.fold_norm = os.environ.get("SLM_FOLD_NORM", "1") != "0"
+        # two half-batch lanes on two streams for pure-decode batches of >= lanes_min tokens (0 = never);
+        # lanes_chain: the lanes' attention launches are serialised by events (see _run_two_lanes)
+        # SLM_DECODE_LANES: "auto" (default: the batch sizes where it was measured to pay, _lane_split),
+        # 0 = never, N = every pure-decode batch of >= N tokens (tests, sweeps)
+        _lm = os.environ.get("SLM_DECODE_LANES", "auto")
+        self.lanes_min = -1 if _lm == "auto" else int(_lm)
+        self.lanes_chain = os.environ.get("SLM_DECODE_LANES_CHAIN", "1") != "0"
+        self._side_stream = None
+        self._lane_bufs = {}
+        self.last_lanes = 1
         tp = pa.world_size
         assert shape.n_heads % tp == 0 and shape.intermediate % tp == 0 and shape.hidden % tp == 0
         self.n_heads = shape.n_heads // tp
@@ -240,15 +251,214 @@ class LlamaDecodeStep:
         need = max(need, 64 * n_tokens * max(2 * s.intermediate // self.pa.world_size, s.hidden) * 4)
         # deferred split-K slabs (o / down / qkv leave up to 16 fp32 slabs for their consumer): both slots
         widest = max(s.hidden, (self.n_heads + 2 * self.n_kv_heads) * s.head_dim)
-        kernels.reserve_workspace(min(need, 4 << 30), self.device,
-                                  deferred_nbytes=16 * n_tokens * widest * 4)
+        for lane in ((0, 1) if self.lanes_min != 0 else (0,)):  # every lane owns its scratch
+            with kernels.workspace_lane(lane):
+                kernels.reserve_workspace(min(need, 4 << 30), self.device,
+                                          deferred_nbytes=16 * n_tokens * widest * 4)
+        if self.lanes_min != 0 and self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+
+    # ------------------------------------------------------------------------------------------
+    # One decoder stack over a range of token rows ("lane").  A step normally has ONE lane (all rows,
+    # the caller's stream).  A large pure-decode batch on a single GPU may run as TWO half-batch lanes
+    # on two streams (round 4, experiment 9 of the round-3 review): the decode attention is HBM-bound
+    # and the int4 GEMMs are matrix-pipe / L2-bound, so one half's GEMMs run under the other half's
+    # attention.  The attention launches of the two lanes are chained by events (A0(l) -> A1(l) ->
+    # A0(l+1) ...): exactly one attention kernel streams the KV cache at any time and each lane's
+    # o_proj / MLP / next qkv projection run meanwhile.  Per-lane scratch (kernels.workspace_lane),
+    # per-lane row slices of the static buffers, the SAME weights and KV cache.  Everything is
+    # ordinary launches + events: capturable into one hipGraph (two branches), so it lives behind
+    # ModelRunner unchanged.
+    # ------------------------------------------------------------------------------------------
+    class _Lane:
+        __slots__ = ("idx", "r0", "r1", "T", "positions", "params", "resid", "alt", "normed", "qkv",
+                     "attn", "act", "gate_up", "o_buf", "down_buf", "pend", "fold", "stream", "q", "ar")
+
+    def _lane_split(self, T: int, params: InputParameters, ar) -> int:
+        """Rows of lane 0 when the step runs as two lanes, else 0.  Two lanes need: one rank, a pure
+        decode batch in the reference's graph-replay sense (every sequence brings exactly one token:
+        q_max_seq_len == 1 and n_tokens == n_seqs, the condition ModelRunner replays on,
+        model_runner.cpp:112-140, under which q_cu_seq_lens is the identity), and enough rows that
+        the half-batch GEMMs stay efficient (SLM_DECODE_LANES: auto / 0 = never / N = from N tokens on)."""
+        n_seqs = params.q_cu_seq_lens.numel() - 1
+        if self.lanes_min == 0 or ar is not None or self.pa.world_size != 1:
+            return 0
+        if params.q_max_seq_len != 1 or T != n_seqs or T < 64:
+            return 0
+        if self.lanes_min < 0:
+            # auto: where two lanes were measured faster on one MI355X (Llama-3-8B shapes, 4 k context,
+            # profiles/r04_lanes_sweep.jsonl): T = 96 +3.2 %, 128 +6.4 %, 160 +1.4 %, 256 +3.4..5.4 %;
+            # slower at 192 (-3.7 %: 96-sequence attention launches fill the CUs badly), 224 (-7 %),
+            # 320 (-6 %), 384 (-2 %): halves beyond 128 rows put BOTH lanes' GEMMs past the
+            # M = 129 tile step, 2 x 157 us instead of one 175-250 us launch set; no change at 64.
+            if not (96 <= T <= 160 or 232 <= T <= 256):
+                return 0
+        elif T < self.lanes_min:
+            return 0
+        return (T // 2 + 31) // 32 * 32
+
+    def _make_lanes(self, T: int, positions, params: InputParameters, o_buf, down_buf, ar, fold):
+        b = self.buf
+        h0 = self._lane_split(T, params, ar)
+        ranges = [(0, T)] if h0 <= 0 or h0 >= T else [(0, h0), (h0, T)]
+        lanes = []
+        for i, (r0, r1) in enumerate(ranges):
+            ln = LlamaDecodeStep._Lane()
+            ln.idx, ln.r0, ln.r1, ln.T = i, r0, r1, r1 - r0
+            ln.positions = positions[r0:r1]
+            if len(ranges) == 1:
+                ln.params = params
+            else:
+                # the lane's own cu arrays, rebased ON THE DEVICE (capture-safe); the block table stays
+                # whole: cu_block_lens keeps its absolute offsets into it
+                st = self._lane_static(i, r1 - r0)
+                torch.sub(params.q_cu_seq_lens[r0:r1 + 1], params.q_cu_seq_lens[r0], out=st["q_cu"])
+                torch.sub(params.kv_cu_seq_lens[r0:r1 + 1], params.kv_cu_seq_lens[r0], out=st["kv_cu"])
+                ln.params = InputParameters(
+                    q_cu_seq_lens=st["q_cu"], kv_cu_seq_lens=st["kv_cu"],
+                    new_cache_slots=params.new_cache_slots[r0:r1], block_tables=params.block_tables,
+                    cu_block_lens=params.cu_block_lens[r0:r1 + 1], q_max_seq_len=params.q_max_seq_len,
+                    kv_max_seq_len=params.kv_max_seq_len)
+            ln.resid, ln.normed = b["resid"][r0:r1], b["normed"][r0:r1]
+            ln.alt = b["resid_alt"][:T] if fold else None
+            ln.qkv, ln.attn, ln.act = b["qkv"][r0:r1], b["attn"][r0:r1], b["act"][r0:r1]
+            ln.gate_up = b["gate_up"][r0:r1] if b["gate_up"] is not None else None
+            ln.o_buf, ln.down_buf = o_buf[r0:r1], down_buf[r0:r1]
+            ln.fold, ln.stream, ln.ar = fold, None, ar
+            lanes.append(ln)
+        return lanes
+
+    def _lane_static(self, i: int, n: int):
+        key = (i, n)
+        st = self._lane_bufs.get(key)
+        if st is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise kernels.SlmError("two-lane decode: run one warm-up step of this batch size before capture")
+            z = lambda: torch.zeros(n + 1, dtype=torch.int32, device=self.device)  # noqa: E731
+            st = self._lane_bufs[key] = {"q_cu": z(), "kv_cu": z()}
+        return st
+
+    def _run_norm(self, ln, pend) -> None:
+        x, deferred, res, weight = pend
+        kernels.rms_norm(ln.normed, x, weight, self.shape.rms_eps, residual=res, partials=deferred)
+
+    def _reduce_add_norm(self, ln, i: int, partial: torch.Tensor, weight: torch.Tensor, deferred=None):
+        """normed = RMSNorm(all-reduce(partial) + resid) * weight, resid updated
+        (reduce_from_model_parallel_region + rms_norm_residual, or the fused launch).
+        Returns the norm still to be run when it may fold into its consumer, else None."""
+        if ln.ar is not None:
+            ln.ar.allreduce_residual_rmsnorm(i, ln.T, ln.normed, ln.resid, weight, self.shape.rms_eps)
+            return None
+        if self.pa.world_size > 1:
+            self.pa.process_group.allreduce(partial)
+        pend = (partial, deferred, ln.resid, weight)
+        if ln.fold:
+            return pend
+        self._run_norm(ln, pend)
+        return None
+
+    def _norm_then(self, ln, lin, pend, out, defer_splitk=False):
+        """lin(RMSNorm(pend)): in one launch when the projection takes the norm as its prologue."""
+        if pend is None:
+            return lin.forward(ln.normed, out=out, defer_splitk=defer_splitk)
+        if not lin.norm_supported(ln.T, defer_splitk):
+            self._run_norm(ln, pend)
+            return lin.forward(ln.normed, out=out, defer_splitk=defer_splitk)
+        x, deferred, res, weight = pend
+        pro = kernels.NormPrologue(weight, self.shape.rms_eps, residual=res, partials=deferred,
+                                   residual_out=ln.alt if res is not None else None)
+        y = lin.forward(x, out=out, defer_splitk=defer_splitk, norm=pro)
+        if res is not None:  # the residual stream now lives in the other buffer
+            ln.resid, ln.alt = ln.alt, ln.resid
+        return y
+
+    def _pre_attn(self, ln, li: int) -> None:
+        """input norm -> fused qkv projection -> RoPE + KV append (everything in front of the paged
+        attention of layer li)."""
+        L, D = self.layers[li], self.shape.head_dim
+        # a split-K GEMM hands its fp32 slabs straight to its consumer (one launch and one
+        # activation round trip less): qkv -> the RoPE + append kernel (any world size: the qkv
+        # projection is column-parallel), o / down -> the RMSNorm (single rank)
+        qkv = self._norm_then(ln, L["qkv"], ln.pend, ln.qkv, defer_splitk=self.defer_splitk)
+        ln.pend = None
+        nq, nkv = self.n_heads * D, self.n_kv_heads * D
+        q, k, v = qkv[:, :nq], qkv[:, nq:nq + nkv], qkv[:, nq + nkv:]
+        ln.q = self.attn.append(q, k, v, ln.positions, L["kv"], ln.params,
+                                qkv_partials=L["qkv"].deferred if self.defer_splitk else None)
+
+    def _attn(self, ln, li: int) -> None:
+        self.attn.decode(ln.q, self.layers[li]["kv"], ln.params, output=ln.attn)
+
+    def _post_attn(self, ln, li: int) -> None:
+        """o_proj -> (reduce) + residual + post-attention norm -> gate_up . SiLU*mul -> down ->
+        (reduce) + residual + the NEXT block's input norm (or the final norm)."""
+        L, pa = self.layers[li], self.pa
+        attn = ln.attn.view(ln.T, -1)
+        defer = pa.world_size == 1 and self.defer_splitk
+        delta = L["o"].forward(attn, out=ln.o_buf, reduce=False, defer_splitk=defer)
+        pend = self._reduce_add_norm(ln, 0, delta, L["post_norm"], L["o"].deferred if defer else None)
+        if L["gate_up"].paired:  # SiLU*mul in the GEMM epilogue
+            self._norm_then(ln, L["gate_up"], pend, ln.act)
+        else:
+            gu = self._norm_then(ln, L["gate_up"], pend, ln.gate_up)
+            kernels.silu_and_mul(ln.act, gu)
+        delta = L["down"].forward(ln.act, out=ln.down_buf, reduce=False, defer_splitk=defer)
+        nxt = self.layers[li + 1]["in_norm"] if li + 1 < len(self.layers) else self.final_norm
+        ln.pend = self._reduce_add_norm(ln, 1, delta, nxt, L["down"].deferred if defer else None)
+
+    def _first_norm(self, ln) -> None:
+        # A norm that has not run yet: (x, deferred slabs of x or None, residual or None, weight).
+        # It either folds into the projection that consumes it (_norm_then) or runs on its own.
+        ln.pend = (ln.resid, None, None, self.layers[0]["in_norm"])
+        if not ln.fold:
+            self._run_norm(ln, ln.pend)
+            ln.pend = None
+
+    def _run_two_lanes(self, l0, l1) -> None:
+        main = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        side = self._side_stream
+        l0.stream, l1.stream = main, side
+        fork = torch.cuda.Event()
+        fork.record(main)
+        side.wait_event(fork)
+
+        def on(ln):
+            st = contextlib.ExitStack()
+            st.enter_context(torch.cuda.stream(ln.stream))
+            st.enter_context(kernels.workspace_lane(ln.idx))
+            return st
+        n = len(self.layers)
+        for ln in (l0, l1):
+            with on(ln):
+                self._first_norm(ln)
+                self._pre_attn(ln, 0)
+        prev = None  # the other lane's previous attention: the token that serialises the KV streams
+        for li in range(n):
+            for ln in (l0, l1):
+                with on(ln):
+                    if prev is not None and self.lanes_chain:
+                        ln.stream.wait_event(prev)
+                    self._attn(ln, li)
+                    prev = torch.cuda.Event()
+                    prev.record(ln.stream)
+                    self._post_attn(ln, li)
+                    if li + 1 < n:
+                        self._pre_attn(ln, li + 1)
+        with on(l1):
+            if l1.pend is not None:
+                self._run_norm(l1, l1.pend)
+                l1.pend = None
+        join = torch.cuda.Event()
+        join.record(side)
+        main.wait_event(join)
 
     def forward(self, tokens: torch.Tensor, positions: torch.Tensor, params: InputParameters,
                 return_logits: bool = False) -> torch.Tensor:
         """tokens/positions [T] int32 -> next-token ids [n_seqs] (greedy), last token per sequence."""
         s, b, pa = self.shape, self.buf, self.pa
         T = tokens.numel()
-        D = s.head_dim
         resid, normed = b["resid"][:T], b["normed"][:T]
         ar = self.custom_ar if pa.world_size > 1 else None
         x = self.embed[tokens.long()]
@@ -271,72 +481,21 @@ class LlamaDecodeStep:
             resid.copy_(x)
             o_buf, down_buf = b["o"][:T], b["down"][:T]
 
-        # A norm that has not run yet: (x, deferred slabs of x or None, residual or None, weight).
-        # It either folds into the projection that consumes it (norm_then) or runs on its own.
         fold = self.fold_norm and pa.world_size == 1 and T <= 4
-        state = {"resid": resid, "alt": b["resid_alt"][:T] if fold else None}
-
-        def run_norm(pend) -> None:
-            x, deferred, res, weight = pend
-            kernels.rms_norm(normed, x, weight, s.rms_eps, residual=res, partials=deferred)
-
-        def reduce_add_norm(i: int, partial: torch.Tensor, weight: torch.Tensor, deferred=None):
-            """normed = RMSNorm(all-reduce(partial) + resid) * weight, resid updated
-            (reduce_from_model_parallel_region + rms_norm_residual, or the fused launch).
-            Returns the norm still to be run when it may fold into its consumer, else None."""
-            if ar is not None:
-                ar.allreduce_residual_rmsnorm(i, T, normed, resid, weight, s.rms_eps)
-                return None
-            if pa.world_size > 1:
-                pa.process_group.allreduce(partial)
-            pend = (partial, deferred, state["resid"], weight)
-            if fold:
-                return pend
-            run_norm(pend)
-            return None
-
-        def norm_then(lin, pend, out, defer_splitk=False):
-            """lin(RMSNorm(pend)): in one launch when the projection takes the norm as its prologue."""
-            if pend is None:
-                return lin.forward(normed, out=out, defer_splitk=defer_splitk)
-            if not lin.norm_supported(T, defer_splitk):
-                run_norm(pend)
-                return lin.forward(normed, out=out, defer_splitk=defer_splitk)
-            x, deferred, res, weight = pend
-            pro = kernels.NormPrologue(weight, s.rms_eps, residual=res, partials=deferred,
-                                       residual_out=state["alt"] if res is not None else None)
-            y = lin.forward(x, out=out, defer_splitk=defer_splitk, norm=pro)
-            if res is not None:  # the residual stream now lives in the other buffer
-                state["resid"], state["alt"] = state["alt"], state["resid"]
-            return y
-
-        pend = (resid, None, None, self.layers[0]["in_norm"])
-        if not fold:
-            run_norm(pend)
-            pend = None
-        for li, L in enumerate(self.layers):
-            # a split-K GEMM hands its fp32 slabs straight to its consumer (one launch and one
-            # activation round trip less): qkv -> the RoPE + append kernel (any world size: the qkv
-            # projection is column-parallel), o / down -> the RMSNorm (single rank)
-            qkv = norm_then(L["qkv"], pend, b["qkv"][:T], defer_splitk=self.defer_splitk)
-            nq, nkv = self.n_heads * D, self.n_kv_heads * D
-            q, k, v = qkv[:, :nq], qkv[:, nq:nq + nkv], qkv[:, nq + nkv:]
-            attn = self.attn.forward(q, k, v, positions, L["kv"], params, output=b["attn"][:T],
-                                     qkv_partials=L["qkv"].deferred if self.defer_splitk else None)
-            defer = pa.world_size == 1 and self.defer_splitk
-            delta = L["o"].forward(attn, out=o_buf, reduce=False, defer_splitk=defer)
-            pend = reduce_add_norm(0, delta, L["post_norm"], L["o"].deferred if defer else None)
-            if L["gate_up"].paired:  # SiLU*mul in the GEMM epilogue
-                norm_then(L["gate_up"], pend, b["act"][:T])
-            else:
-                gu = norm_then(L["gate_up"], pend, b["gate_up"][:T])
-                kernels.silu_and_mul(b["act"][:T], gu)
-            delta = L["down"].forward(b["act"][:T], out=down_buf, reduce=False, defer_splitk=defer)
-            # the NEXT block's input norm (or the final norm) consumes this reduction
-            nxt = self.layers[li + 1]["in_norm"] if li + 1 < len(self.layers) else self.final_norm
-            pend = reduce_add_norm(1, delta, nxt, L["down"].deferred if defer else None)
-        if pend is not None:  # the final norm has no projection of ours behind it
-            run_norm(pend)
+        lanes = self._make_lanes(T, positions, params, o_buf, down_buf, ar, fold)
+        self.last_lanes = len(lanes)
+        if len(lanes) == 2:
+            self._run_two_lanes(lanes[0], lanes[1])
+        else:
+            ln = lanes[0]
+            self._first_norm(ln)
+            for li in range(len(self.layers)):
+                self._pre_attn(ln, li)
+                self._attn(ln, li)
+                self._post_attn(ln, li)
+        for ln in lanes:
+            if ln.pend is not None:  # the final norm has no projection of ours behind it
+                self._run_norm(ln, ln.pend)
         last = (params.q_cu_seq_lens[1:] - 1).long()
         self.last_hidden = normed[last]  # final-norm output of each sequence's last token (tests)
         logits = self.last_hidden @ self.lm_head  # plain library GEMM (hipBLASLt): not on the graded path

@@ -95,8 +95,24 @@ _retired = []  # buffers replaced by bigger ones: still referenced by graphs cap
 _deferred_gen = {}  # (device, slot) -> generation counter of that deferred-partials buffer
 
 
+_lane = 0  # scratch lane of the calling code path (workspace_lane): 0 unless a step runs two streams
+
+
 def _dev_key(dev: torch.device):
-    return (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    return (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), _lane)
+
+
+@contextlib.contextmanager
+def workspace_lane(lane: int):
+    """Scratch buffers are per (device, lane).  Kernels launched on DIFFERENT streams that may run
+    concurrently (the two half-batch lanes of decode.LlamaDecodeStep) must not share the split-KV /
+    split-K scratch: each stream's launches are issued inside its own lane.  Lane 0 is the default."""
+    global _lane
+    prev, _lane = _lane, int(lane)
+    try:
+        yield
+    finally:
+        _lane = prev
 
 
 def _grow(table, nbytes: int, dev: torch.device, what: str) -> torch.Tensor:

@@ -120,12 +120,10 @@ class Attention:
         self.n_heads, self.n_kv_heads, self.head_dim = n_heads, n_kv_heads, head_dim
         self.handler, self.sliding_window = handler, sliding_window
 
-    def forward(self, query, key, value, positions, kv_cache: KVCache,
-                input_params: InputParameters, output: Optional[torch.Tensor] = None,
-                qkv_partials=None):
-        """qkv_partials (truthy kernels.DeferredPartials): query / key / value are the column slices
-        of a fused qkv GEMM output that was left as split-K slabs (ColumnParallelQLinear.forward(
-        defer_splitk=True)); the RoPE + append kernel sums them."""
+    def append(self, query, key, value, positions, kv_cache: KVCache, input_params: InputParameters,
+               qkv_partials=None):
+        """First half of forward(): RoPE + KV append (attention.cpp:36-39).  Returns the [T, H, D] view
+        of the (rotated) query for decode()."""
         self.handler.qkv_partials = qkv_partials if qkv_partials else None
         T = query.size(0)
         q = query.view(T, self.n_heads, self.head_dim)
@@ -133,10 +131,25 @@ class Attention:
         v = value.view(T, self.n_kv_heads, self.head_dim)
         q, k = self.handler.apply_pos_emb(q, k, positions)
         self.handler.append_kv_cache(kv_cache, q, k, v, input_params)
+        return q
+
+    def decode(self, q, kv_cache: KVCache, input_params: InputParameters,
+               output: Optional[torch.Tensor] = None):
+        """Second half of forward(): the paged attention itself (attention.cpp:41-42)."""
+        T = q.size(0)
         if output is None:
-            output = torch.empty(T, self.n_heads, self.head_dim, dtype=query.dtype, device=query.device)
+            output = torch.empty(T, self.n_heads, self.head_dim, dtype=q.dtype, device=q.device)
         self.handler.batch_decode(q, kv_cache, input_params, self.sliding_window, output)
         return output.view(T, self.n_heads * self.head_dim)
+
+    def forward(self, query, key, value, positions, kv_cache: KVCache,
+                input_params: InputParameters, output: Optional[torch.Tensor] = None,
+                qkv_partials=None):
+        """qkv_partials (truthy kernels.DeferredPartials): query / key / value are the column slices
+        of a fused qkv GEMM output that was left as split-K slabs (ColumnParallelQLinear.forward(
+        defer_splitk=True)); the RoPE + append kernel sums them."""
+        q = self.append(query, key, value, positions, kv_cache, input_params, qkv_partials)
+        return self.decode(q, kv_cache, input_params, output)
 
 
 # ---------------------------------------------------------------------------------------

@@ -1,0 +1,123 @@
+"""Two half-batch lanes on two streams (round 4: the overlap experiment of the round-3 review, item 9).
+
+A large pure-decode step may run as two lanes: rows [0, h) and [h, T) each walk the decoder stack on
+their own stream with their own scratch, the lanes' attention launches chained by events so that one
+half's int4 GEMMs run under the other half's HBM-bound attention (decode.LlamaDecodeStep._run_two_lanes).
+Same kernels, same weights, same KV cache -- so
+
+  * every lane must give BIT FOR BIT what a single-lane step over that half of the batch alone gives
+    (same row count => same launch plans), eagerly and as ONE replayed hipGraph behind ModelRunner;
+  * against the single-lane step over the whole batch (other row count => other GEMM plans) the logits
+    agree to rounding;
+  * batches the lanes do not cover (prefill rows, verify rows, short batches) run single-lane."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_model_runner_gpu import _batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _model(max_tokens, n_blocks, B, seed=3):
+    from scalellm_amd.decode import LlamaDecodeStep, LlamaShape
+    shape = LlamaShape.tiny()
+    model = LlamaDecodeStep(shape, max_tokens, n_blocks, B, quant_method="awq", group_size=128,
+                            dtype=torch.bfloat16, device=DEV, seed=seed)
+    g = torch.Generator(device=DEV).manual_seed(seed + 100)
+    for L in model.layers:
+        L["kv"].key_cache.normal_(generator=g)
+        L["kv"].value_cache.normal_(generator=g)
+    return model, shape
+
+
+def _slice_params(params, r0, r1):
+    """The half batch as its OWN batch in engine format (cu arrays rebased on the host, block table
+    sliced): what the lane has to reproduce."""
+    q_cu, kv_cu, bcu = (t.cpu().numpy() for t in (params.q_cu_seq_lens, params.kv_cu_seq_lens, params.cu_block_lens))
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.int32, device=DEV)  # noqa: E731
+    return dataclasses.replace(
+        params, q_cu_seq_lens=t(q_cu[r0:r1 + 1] - q_cu[r0]), kv_cu_seq_lens=t(kv_cu[r0:r1 + 1] - kv_cu[r0]),
+        new_cache_slots=params.new_cache_slots[r0:r1].clone(),
+        block_tables=params.block_tables[bcu[r0]:bcu[r1]].clone(), cu_block_lens=t(bcu[r0:r1 + 1] - bcu[r0]))
+
+
+@pytest.mark.parametrize("bs,chain", [(96, True), (160, True), (96, False)])
+def test_two_lanes_equal_the_half_batches_bit_for_bit_eager_and_replayed(bs, chain):
+    from scalellm_amd.model_runner import ModelRunner, ModelRunnerOptions
+    B, max_len, n_blocks = 16, 496, 160 * 32
+    model, shape = _model(bs, n_blocks, B)
+    rng = np.random.default_rng(bs)
+    kv = [int(x) for x in rng.integers(1, 450, size=bs)]
+    tokens, positions, params = _batch(rng, bs, 1, kv, B, n_blocks, shape.vocab)
+    snap = [(L["kv"].key_cache.clone(), L["kv"].value_cache.clone()) for L in model.layers]
+
+    def restore():
+        for L, (k0, v0) in zip(model.layers, snap):
+            L["kv"].key_cache.copy_(k0)
+            L["kv"].value_cache.copy_(v0)
+
+    model.lanes_min = 0
+    whole = model.forward(tokens, positions, params, return_logits=True).float().clone()
+    assert model.last_lanes == 1
+    restore()
+    model.lanes_min, model.lanes_chain = 64, chain
+    model.reserve_workspaces(bs, max_len)
+    got = model.forward(tokens, positions, params, return_logits=True).clone()
+    torch.cuda.synchronize()
+    assert model.last_lanes == 2
+    restore()
+    h = model._lane_split(bs, params, None)
+    assert 0 < h < bs and h % 32 == 0
+    model.lanes_min = 0
+    for r0, r1 in ((0, h), (h, bs)):
+        half = model.forward(tokens[r0:r1], positions[r0:r1], _slice_params(params, r0, r1), return_logits=True)
+        torch.cuda.synchronize()
+        assert torch.equal(got[r0:r1], half), f"lane rows [{r0}, {r1}): max |diff| " \
+                                              f"{(got[r0:r1].float() - half.float()).abs().max().item()}"
+        restore()
+    rel = float((got.float() - whole).norm() / whole.norm())
+    assert rel <= 2e-2, rel
+    # ... and behind ModelRunner: ONE captured graph (two branches) replayed on another batch of that size
+    model.lanes_min = 64
+    opts = ModelRunnerOptions(block_size=B, cuda_graph_max_seq_len=max_len, cuda_graph_batch_sizes=[bs],
+                              num_decoding_tokens=1)
+    runner = ModelRunner(model, DEV, opts, return_logits=True)
+    runner.capture_cuda_graphs(bs)
+    restore()
+    for trial in range(2):
+        kv2 = [int(x) for x in rng.integers(1, max_len, size=bs)]
+        t2, p2, prm2 = _batch(rng, bs, 1, kv2, B, n_blocks, shape.vocab)
+        hinted = dataclasses.replace(prm2, kv_max_seq_len=max_len)
+        want = model.forward(t2, p2, hinted, return_logits=True).clone()
+        assert model.last_lanes == 2
+        restore()
+        before = runner.num_graph_replayed
+        out = runner.forward(t2, p2, prm2)
+        torch.cuda.synchronize()
+        assert runner.num_graph_replayed == before + 1
+        assert torch.equal(out, want), (trial, float((out.float() - want.float()).abs().max()))
+        restore()
+
+
+def test_lanes_only_cover_pure_decode_batches_of_the_minimum_size():
+    B, n_blocks = 16, 600
+    model, shape = _model(320, n_blocks, B, seed=5)
+    model.lanes_min = 64
+    rng = np.random.default_rng(0)
+    # (a) too few rows
+    t, p, prm = _batch(rng, 8, 1, [40] * 8, B, n_blocks, shape.vocab)
+    model.forward(t, p, prm)
+    assert model.last_lanes == 1
+    # (b) verify rows (4 tokens per sequence) and a prefill chunk: not the identity q_cu
+    t, p, prm = _batch(rng, 20, 4, [50] * 20, B, n_blocks, shape.vocab)
+    model.forward(t, p, prm)
+    assert model.last_lanes == 1
+    # (c) pure decode, enough rows
+    t, p, prm = _batch(rng, 64, 1, [33] * 64, B, n_blocks, shape.vocab)
+    model.forward(t, p, prm)
+    torch.cuda.synchronize()
+    assert model.last_lanes == 2
