@@ -462,6 +462,9 @@ def main():
                     "per sequence, so kv_len grows by one per step from --seqlen")
     ap.add_argument("--lanes", type=int, default=-1, help="two half-batch lanes on two streams for pure-decode "
                     "batches of >= N tokens (0 = never; default: SLM_DECODE_LANES or the library's auto policy)")
+    ap.add_argument("--host", default="py", choices=["py", "cpp"], help="who composes the step: the Python mirror "
+                    "(decode.LlamaDecodeStep over ctypes) or the compiled C++ host step (csrc/shim/slm_llama_hip.cpp "
+                    "through _slm_shim.so); same kernels, same launch sequence -- under graph replay the same line")
     ap.add_argument("--simulate-tp", type=int, default=0, help="tuning aid: run rank 0's shard of a "
                     "TP=N step on one GPU with the collectives stubbed (flagged in the output)")
     args = ap.parse_args()
@@ -512,17 +515,30 @@ def main():
             log=lambda m: print(f"[bench] {m}", file=sys.stderr))
     model = LlamaDecodeStep(shape, bs, n_blocks, B, pa, quant_method=quant, group_size=128,
                             dtype=torch.bfloat16, device=device, seed=0, kv_fill=args.kv_fill,
-                            custom_allreduce=custom_ar, gptq_sym=gptq_sym, bits=args.bits)
+                            custom_allreduce=custom_ar, gptq_sym=gptq_sym, bits=args.bits,
+                            keep_checkpoint=args.host == "cpp")
     if args.lanes >= 0:
         model.lanes_min = args.lanes
     model.reserve_workspaces(bs, L)
+    cpp_model = cpp_prm = None
+    if args.host == "cpp":
+        if world != 1 or args.simulate_tp > 1 or args.bits != 4:
+            raise SystemExit("--host cpp: single GPU, 4-bit weights")
+        from scalellm_amd import cpp_host
+        cpp_model = cpp_host.from_decode_step(model, B, bs, fused=True, lanes=model.lanes_min)
+        cpp_prm = cpp_host.cpp_params(params)
+        model.ckpt = None   # the checkpoint-format copies are packed on both sides now
     torch.cuda.synchronize()
     t_init = time.perf_counter() - t_init
 
     static_tokens = tokens.clone()
 
     def step():
-        nxt = model.forward(static_tokens, positions, params)
+        if cpp_model is not None:
+            nxt = cpp_model.decode_step(static_tokens, positions, cpp_prm)
+            model.last_lanes = cpp_model.last_lanes()
+        else:
+            nxt = model.forward(static_tokens, positions, params)
         static_tokens.copy_(nxt)  # greedy feedback: next step consumes this step's tokens
         if args.advance:  # next step's positions / slots / kv_cu_lens built on the device (f4)
             kernels.decode_advance(positions, params.kv_cu_seq_lens, params.new_cache_slots,
@@ -659,7 +675,9 @@ def main():
                        "model": args.model,
                        "global_batch": bs, "seq_len": L,
                        "parallelism": f"tp{world}" if world > 1 else "single-gpu",
-                       "hip_graph": graph is not None, "decode_lanes": model.last_lanes, "reduced_model": reduced,
+                       "hip_graph": graph is not None, "decode_lanes": model.last_lanes,
+                       "host": "c++ (slm::LlamaForCausalLMHip, _slm_shim.so)" if cpp_model is not None
+                               else "python mirror (decode.LlamaDecodeStep over ctypes)", "reduced_model": reduced,
                        "row_parallel_reduce": (None if world == 1 else
                                                "xgmi two-shot all-reduce fused with residual+rmsnorm "
                                                "(embedding gather and greedy sampling exchange through "

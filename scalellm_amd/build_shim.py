@@ -26,8 +26,8 @@ def build(force: bool = False) -> str:
 
     from . import build as slm_build
     slm_build.build()
-    srcs = [os.path.join(SHIM, f) for f in ("slm_torch_shim.cpp", "slm_qlinear_hip.cpp", "slm_attn_handler_hip.cpp", "slm_shim_pybind.cpp")]
-    deps = srcs + [os.path.join(SHIM, "slm_torch_shim.h"), os.path.join(SHIM, "slm_qlinear_hip.h"), os.path.join(SHIM, "slm_attn_handler_hip.h"),
+    srcs = [os.path.join(SHIM, f) for f in ("slm_torch_shim.cpp", "slm_qlinear_hip.cpp", "slm_attn_handler_hip.cpp", "slm_llama_hip.cpp", "slm_shim_pybind.cpp")]
+    deps = srcs + [os.path.join(SHIM, "slm_torch_shim.h"), os.path.join(SHIM, "slm_qlinear_hip.h"), os.path.join(SHIM, "slm_attn_handler_hip.h"), os.path.join(SHIM, "slm_llama_hip.h"),
                    os.path.join(ROOT, "include", "slm_hip.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) > os.path.getmtime(d) for d in deps):
         return OUT

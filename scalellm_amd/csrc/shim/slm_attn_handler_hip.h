@@ -33,6 +33,10 @@ class KVCache final {
   KVCache() = default;
   KVCache(int64_t n_blocks, int64_t block_size, int64_t n_kv_heads, int64_t head_dim,
           const torch::TensorOptions& options);
+  // over tensors somebody else allocated (kv_cache.h:14: KVCache(key_cache, value_cache)); the
+  // block size is not recoverable from the flat [n_slots, n_kv_heads, head_dim] shape
+  KVCache(torch::Tensor key_cache, torch::Tensor value_cache, int64_t block_size)
+      : block_size_(block_size), key_cache_(std::move(key_cache)), value_cache_(std::move(value_cache)) {}
   bool empty() const { return block_size_ == 0; }
   int64_t block_size() const { return block_size_; }
   std::tuple<torch::Tensor, torch::Tensor> get_kv_cache() const { return {key_cache_, value_cache_}; }
@@ -95,6 +99,16 @@ class HipAttnHandler : public AttentionHandler {
                     torch::Tensor& output) override;
   void append_kv_cache(KVCache& kv_cache, const torch::Tensor& key, const torch::Tensor& value,
                        const InputParameters& input_params) override;
+  // what a fused caller needs (the RoPE + append kernel that also sums the qkv GEMM's split-K slabs,
+  // per-stream attention scratch: csrc/shim/slm_llama_hip.cpp)
+  const torch::Tensor& cos_sin_cache() const { return cos_sin_cache_; }
+  // replace the table (fp32 [max_position, rotary_dim] = cos | sin): parity tests share ONE table
+  // between this class and the Python mirror (cos / sin evaluated on different devices differ in ulps)
+  void set_cos_sin_cache(const torch::Tensor& t) { cos_sin_cache_ = t; }
+  int64_t rotary_dim() const { return rotary_dim_; }
+  bool interleaved() const { return interleaved_; }
+  float sm_scale() const { return sm_scale_; }
+  float logits_soft_cap() const { return logits_soft_cap_; }
 
  private:
   float sm_scale_ = 0.f;

@@ -112,23 +112,33 @@ void QLinearHipBase::verify_loaded_weights(const std::string& prefix) const {
     TORCH_CHECK(g_idx_is_loaded_ || packed_, "g_idx is not loaded for ", prefix + "g_idx");
 }
 
+void QLinearHipBase::ensure_packed() {
+  if (packed_) return;  // repack at the first call, like the reference (weight_repacked_)
+  verify_loaded_weights();
+  const int64_t per = 32 / quant_args_.bits();  // values per int32
+  const int64_t K = awq_ ? qweight_.size(0) : qweight_.size(0) * per;
+  const int64_t N = awq_ ? qweight_.size(1) * per : qweight_.size(1);
+  TORCH_CHECK(K == local_in_ && N == local_out_, "loaded qweight is [", K, ", ", N, "], expected [",
+              local_in_, ", ", local_out_, "]");
+  const int64_t gs = quant_args_.group_size() > 0 ? quant_args_.group_size() : K;
+  std::optional<torch::Tensor> gi;
+  if (g_idx_.defined() && g_idx_.numel() > 0) gi = g_idx_;
+  packed_ = std::make_unique<W4Linear>(awq_ ? "awq" : "gptq", qweight_, qzeros_,
+                                       scales_.to(options_.dtype()), gi, gs, quant_args_.bits(), paired_);
+  // the checkpoint-format shards are no longer needed
+  qweight_ = torch::Tensor(); qzeros_ = torch::Tensor(); scales_ = torch::Tensor(); g_idx_ = torch::Tensor();
+  if (has_bias_) bias_ = bias_.to(options_.dtype()).contiguous();
+}
+
+W4Linear& QLinearHipBase::packed() {
+  ensure_packed();
+  return *packed_;
+}
+
 torch::Tensor QLinearHipBase::gemm(const torch::Tensor& input, const std::optional<torch::Tensor>& bias) {
-  if (!packed_) {  // repack at the first call, like the reference (weight_repacked_)
-    verify_loaded_weights();
-    const int64_t per = 32 / quant_args_.bits();  // values per int32
-    const int64_t K = awq_ ? qweight_.size(0) : qweight_.size(0) * per;
-    const int64_t N = awq_ ? qweight_.size(1) * per : qweight_.size(1);
-    TORCH_CHECK(K == local_in_ && N == local_out_, "loaded qweight is [", K, ", ", N, "], expected [",
-                local_in_, ", ", local_out_, "]");
-    const int64_t gs = quant_args_.group_size() > 0 ? quant_args_.group_size() : K;
-    std::optional<torch::Tensor> gi;
-    if (g_idx_.defined() && g_idx_.numel() > 0) gi = g_idx_;
-    packed_ = std::make_unique<W4Linear>(awq_ ? "awq" : "gptq", qweight_, qzeros_,
-                                         scales_.to(options_.dtype()), gi, gs, quant_args_.bits());
-    // the checkpoint-format shards are no longer needed
-    qweight_ = torch::Tensor(); qzeros_ = torch::Tensor(); scales_ = torch::Tensor(); g_idx_ = torch::Tensor();
-    if (has_bias_) bias_ = bias_.to(options_.dtype()).contiguous();
-  }
+  ensure_packed();
+  // (a paired weight through the plain interface returns its columns in packed order: only the
+  // fused decoder layer sets it, and it calls forward_into)
   return packed_->forward(input, bias);
 }
 

@@ -101,6 +101,13 @@ class QLinearHipBase : public ParallelLinearImpl {
   void verify_loaded_weights(const std::string& prefix = "") const override;
   // checkpoint-format tensors of THIS rank's shard (testing)
   torch::Tensor qweight() const { return qweight_; }
+  // The merged gate|up projection of the MLP: pack it paired so the SiLU*mul of
+  // kernel::act_and_mul runs in the GEMM epilogue (before the first forward)
+  void set_act_mul_silu() { TORCH_CHECK(!packed_, "set_act_mul_silu after the repack"); paired_ = true; }
+  // the packed weight (repacked on first use, like forward) -- for the fused calls of a decoder
+  // layer (W4Linear::forward_into: deferred split-K, SiLU*mul epilogue, caller-owned scratch)
+  W4Linear& packed();
+  bool has_bias() const { return has_bias_; }
 
  protected:
   QLinearHipBase(int64_t in_features, int64_t out_features, bool bias, const QuantArgs& quant_args,
@@ -110,12 +117,13 @@ class QLinearHipBase : public ParallelLinearImpl {
   void load_fused(const StateDict& sd, const std::vector<std::string>& prefixes, const std::string& name,
                   int64_t dim, std::vector<torch::Tensor>& parts, torch::Tensor& dst, bool& loaded);
   torch::Tensor gemm(const torch::Tensor& input, const std::optional<torch::Tensor>& bias);
+  void ensure_packed();
 
   int64_t in_features_, out_features_;
   QuantArgs quant_args_;
   ParallelArgs parallel_args_;
   torch::TensorOptions options_;
-  bool awq_ = false, has_bias_ = false;
+  bool awq_ = false, has_bias_ = false, paired_ = false;
   // checkpoint-format shards (released once repacked)
   torch::Tensor qweight_, qzeros_, scales_, g_idx_, bias_;
   bool qweight_is_loaded_ = false, qzeros_is_loaded_ = false, scales_is_loaded_ = false,

@@ -8,6 +8,7 @@
 #include <thread>
 
 #include "slm_attn_handler_hip.h"
+#include "slm_llama_hip.h"
 #include "slm_qlinear_hip.h"
 #include "slm_torch_shim.h"
 
@@ -162,6 +163,63 @@ PYBIND11_MODULE(_slm_shim, m) {
           std::tie(q, k) = h.apply_pos_emb(q, k, positions);
           h.append_kv_cache(kv_cache, k, v, params);
         });
+  // the C++ HOST STEP: slm::LlamaForCausalLMHip (csrc/shim/slm_llama_hip.h = the decoder stack of
+  // src/models/meta/llama.h:123-345 composed from the C++ layer classes above) with the KV caches a
+  // Worker would own.  tests/test_shim_gpu.py holds it bit-identical to decode.LlamaDecodeStep;
+  // bench.py --host cpp times it.
+  struct PyLlama {
+    std::unique_ptr<slm::LlamaForCausalLMHip> model;
+    std::vector<slm::KVCache> kv;
+  };
+  py::class_<PyLlama>(m, "LlamaForCausalLMHip")
+      .def(py::init([make_args](int64_t hidden, int64_t n_heads, int64_t n_kv_heads, int64_t head_dim,
+                                int64_t intermediate, int64_t n_layers, int64_t vocab, int64_t max_position,
+                                double rope_theta, double rms_eps, const std::string& quant_method, int64_t bits,
+                                int64_t group_size, bool desc_act, int64_t max_tokens, bool fused,
+                                int64_t decode_lanes, bool lanes_chain, torch::ScalarType dtype, int device_index) {
+             slm::LlamaArgs a;
+             a.hidden_size = hidden; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.head_dim = head_dim;
+             a.intermediate_size = intermediate; a.n_layers = n_layers; a.vocab_size = vocab;
+             a.max_position_embeddings = max_position; a.rope_theta = static_cast<float>(rope_theta);
+             a.rms_norm_eps = static_cast<float>(rms_eps);
+             slm::LlamaForCausalLMHip::Options o;
+             o.max_tokens = max_tokens; o.fused = fused; o.decode_lanes = decode_lanes; o.lanes_chain = lanes_chain;
+             const bool awq = quant_method == "awq";
+             auto p = std::make_unique<PyLlama>();
+             p->model = std::make_unique<slm::LlamaForCausalLMHip>(
+                 a, make_args(quant_method, bits, group_size, desc_act, /*is_sym=*/false, /*zero_point=*/awq),
+                 slm::ParallelArgs(0, 1, nullptr), torch::dtype(dtype).device(torch::Device(torch::kCUDA, device_index)),
+                 o);
+             return p;
+           }),
+           py::arg("hidden"), py::arg("n_heads"), py::arg("n_kv_heads"), py::arg("head_dim"), py::arg("intermediate"),
+           py::arg("n_layers"), py::arg("vocab"), py::arg("max_position"), py::arg("rope_theta"), py::arg("rms_eps"),
+           py::arg("quant_method"), py::arg("bits"), py::arg("group_size"), py::arg("desc_act"), py::arg("max_tokens"),
+           py::arg("fused") = true, py::arg("decode_lanes") = -1, py::arg("lanes_chain") = true,
+           py::arg("dtype") = torch::kBFloat16, py::arg("device_index") = 0)
+      .def("load_state_dict",
+           [](PyLlama& self, std::unordered_map<std::string, torch::Tensor> sd) {
+             self.model->load_state_dict(slm::StateDict(std::move(sd)));
+           })
+      .def("verify_loaded_weights", [](PyLlama& self) { self.model->verify_loaded_weights(); })
+      // the engine-owned caches: one (key_cache, value_cache) pair per layer, shared, not copied
+      .def("set_kv_caches",
+           [](PyLlama& self, const std::vector<std::pair<torch::Tensor, torch::Tensor>>& caches, int64_t block_size) {
+             self.kv.clear();
+             for (const auto& kvp : caches) self.kv.emplace_back(kvp.first, kvp.second, block_size);
+           })
+      .def("set_cos_sin_cache", [](PyLlama& self, const torch::Tensor& t) { self.model->handler().set_cos_sin_cache(t); })
+      .def("reserve", [](PyLlama& self, int64_t n_tokens) { self.model->reserve(n_tokens); })
+      .def("decode_step",
+           [](PyLlama& self, const torch::Tensor& tokens, const torch::Tensor& positions,
+              const slm::InputParameters& params, bool return_logits) {
+             return self.model->decode_step(tokens, positions, self.kv, params, return_logits);
+           },
+           py::arg("tokens"), py::arg("positions"), py::arg("params"), py::arg("return_logits") = false)
+      .def("forward",
+           [](PyLlama& self, const torch::Tensor& tokens, const torch::Tensor& positions,
+              const slm::InputParameters& params) { return self.model->forward(tokens, positions, self.kv, params); })
+      .def("last_lanes", [](PyLlama& self) { return self.model->last_lanes(); });
   py::class_<slm::W4Linear>(m, "W4Linear")
       .def(py::init<const std::string&, const torch::Tensor&, const torch::Tensor&,
                     const torch::Tensor&, const std::optional<torch::Tensor>&, int64_t, int64_t>(),

@@ -490,8 +490,10 @@ size_t marlin_sz_cache_entries() {
 
 W4Linear::W4Linear(const std::string& quant_method, const torch::Tensor& qweight,
                    const torch::Tensor& qzeros, const torch::Tensor& scales,
-                   const std::optional<torch::Tensor>& g_idx, int64_t group_size, int64_t bits) {
+                   const std::optional<torch::Tensor>& g_idx, int64_t group_size, int64_t bits, bool paired) {
   const bool awq = quant_method == "awq";
+  paired_ = paired;
+  TORCH_CHECK(!paired || bits == 4, "paired (gate | up) packing is built for 4-bit weights");
   TORCH_CHECK(awq || quant_method == "gptq", "quant_method must be awq or gptq");
   TORCH_CHECK(bits == 4 || bits == 8, "bits must be 4 or 8, got ", bits);
   c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(qweight.device());
@@ -512,6 +514,7 @@ W4Linear::W4Linear(const std::string& quant_method, const torch::Tensor& qweight
         // qweight / g_idx, FULL scales: qlinear_gptq_marlin_impl.cpp:236-243,270-276; the reference
         // then runs Marlin with is_k_full = false, :319)
         TORCH_CHECK(bits == 4, "act-order shards with uneven groups are supported for 4-bit weights only");
+        TORCH_CHECK(!paired, "paired (gate | up) packing of an act-order shard with uneven groups is not supported");
         pack_uneven_groups(qweight, qzeros, scales, gi, perm);
         return;
       }
@@ -553,7 +556,8 @@ W4Linear::W4Linear(const std::string& quant_method, const torch::Tensor& qweight
   wq_ = torch::empty({static_cast<int64_t>(wb / 4)}, iopt);
   sz_ = torch::empty({static_cast<int64_t>(sb / 4)}, iopt);
   const auto qw = qweight.contiguous(), qz = qzeros.contiguous(), sc = scales.contiguous();
-  check(slm_w4_prepack(awq ? SLM_W4_AWQ : SLM_W4_GPTQ, qw.const_data_ptr<int32_t>(),
+  if (paired) TORCH_CHECK(N_ % 64 == 0, "paired (gate | up) prepack needs N % 64 == 0, got N = ", N_);
+  check(slm_w4_prepack((awq ? SLM_W4_AWQ : SLM_W4_GPTQ) | (paired ? SLM_W4_PAIRED : 0), qw.const_data_ptr<int32_t>(),
                        qz.const_data_ptr<int32_t>(), sc.const_data_ptr(),
                        perm_.defined() ? perm_.const_data_ptr<int32_t>() : nullptr, K_, N_,
                        group_size_, dtype_code(sc), wq_.mutable_data_ptr(), sz_.mutable_data_ptr(),
@@ -633,6 +637,59 @@ torch::Tensor W4Linear::forward(const torch::Tensor& input, const std::optional<
   }
   check(slm_w4a16_gemm(&g, current_stream(a)), "slm_w4a16_gemm");
   return c;
+}
+
+namespace {
+slm_w4_gemm_args w4_args(const torch::Tensor& a, const void* wq, const void* sz, const int32_t* perm, void* c,
+                         int64_t ldc, int64_t K, int64_t N, int64_t gs, int flags) {
+  slm_w4_gemm_args g{};
+  g.a = a.defined() ? a.const_data_ptr() : nullptr;
+  g.wq = wq; g.sz = sz; g.perm = perm; g.bias = nullptr; g.c = c;
+  g.M = a.defined() ? a.size(0) : 0; g.K = K; g.N = N;
+  g.lda = a.defined() ? a.stride(0) : K; g.ldc = ldc;
+  g.group_size = gs;
+  g.dtype = a.defined() ? dtype_code(a) : SLM_BF16;
+  g.flags = flags;
+  return g;
+}
+}  // namespace
+
+size_t W4Linear::workspace_bytes(int64_t M, int flags) const {
+  slm_w4_gemm_args g{};
+  g.wq = wq_.const_data_ptr(); g.sz = sz_.const_data_ptr();
+  g.perm = perm_.defined() ? perm_.const_data_ptr<int32_t>() : nullptr;
+  g.M = M; g.K = K_; g.N = N_; g.lda = k_src_; g.ldc = (flags & SLM_W4_SILU_MUL) ? N_ / 2 : N_;
+  g.group_size = group_size_;
+  g.dtype = dtype_ == torch::kBFloat16 ? SLM_BF16 : SLM_F16;
+  g.flags = flags;
+  if ((flags & SLM_W4_DEFER_REDUCE) && !slm_w4a16_gemm_deferred_splits(&g)) g.flags &= ~SLM_W4_DEFER_REDUCE;
+  return slm_w4a16_gemm_workspace_bytes(&g);
+}
+
+int W4Linear::forward_into(const torch::Tensor& a, torch::Tensor& c, int flags, const torch::Tensor& workspace) const {
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(a.device());
+  TORCH_CHECK(a.dim() == 2 && a.size(1) == k_src_ && a.stride(1) == 1 && a.scalar_type() == dtype_);
+  TORCH_CHECK(!(flags & SLM_W4_SILU_MUL) || paired_, "SLM_W4_SILU_MUL needs weights packed paired");
+  const int64_t n_out = (flags & SLM_W4_SILU_MUL) ? N_ / 2 : N_;
+  TORCH_CHECK(c.dim() == 2 && c.size(0) == a.size(0) && c.size(1) == n_out && c.stride(1) == 1);
+  auto g = w4_args(a, wq_.const_data_ptr(), sz_.const_data_ptr(),
+                   perm_.defined() ? perm_.const_data_ptr<int32_t>() : nullptr, c.mutable_data_ptr(), c.stride(0), K_,
+                   N_, group_size_, flags);
+  if (g.M == 0) return 0;
+  int deferred = 0;
+  if (flags & SLM_W4_DEFER_REDUCE) {
+    deferred = slm_w4a16_gemm_deferred_splits(&g);
+    if (!deferred) g.flags &= ~SLM_W4_DEFER_REDUCE;
+  }
+  const size_t need = slm_w4a16_gemm_workspace_bytes(&g);
+  if (need > 0) {
+    TORCH_CHECK(workspace.defined() && static_cast<size_t>(workspace.nbytes()) >= need,
+                "W4Linear::forward_into: scratch of ", need, " bytes needed (reserve it before the step)");
+    g.workspace = workspace.mutable_data_ptr();
+    g.workspace_bytes = workspace.nbytes();
+  }
+  check(slm_w4a16_gemm(&g, current_stream(a)), "slm_w4a16_gemm");
+  return deferred;
 }
 
 torch::Tensor W4Linear::dequantize() const {

@@ -120,14 +120,28 @@ class W4Linear {
   // quant_method "gptq": qweight [K/8, N], qzeros [G, N/8], scales [G, N], optional g_idx [K]
   // bits = 8: 4 values per int32 instead of 8 (byte order [0,2,1,3] for AWQ); packed as two int4
   // planes over 2K rows (include/slm_hip.h section 3b), same forward()
+  // paired: the tensors are a merged [gate | up] column-parallel weight (multi_parallel_linear.cpp
+  // :14-41); packed with SLM_W4_PAIRED so that forward_into(.., SLM_W4_SILU_MUL, ..) can apply
+  // act_and_mul in the GEMM epilogue (4-bit, evenly grouped weights only)
   W4Linear(const std::string& quant_method, const torch::Tensor& qweight,
            const torch::Tensor& qzeros, const torch::Tensor& scales,
-           const std::optional<torch::Tensor>& g_idx, int64_t group_size, int64_t bits = 4);
+           const std::optional<torch::Tensor>& g_idx, int64_t group_size, int64_t bits = 4,
+           bool paired = false);
 
   // C[M, N] = A[M, K] . dequant(W) (+ bias); `out` may be pre-allocated
   torch::Tensor forward(const torch::Tensor& input, const std::optional<torch::Tensor>& bias,
                         std::optional<torch::Tensor> out = std::nullopt) const;
   torch::Tensor dequantize() const;  // dense [K, N] (debug / parity)
+
+  // The fused forms a decoder layer uses (csrc/shim/slm_llama_hip.cpp), scratch owned by the CALLER
+  // (a step that runs two streams keeps one scratch per stream): C = A . dequant(W) with
+  // flags = SLM_W4_DEFER_REDUCE (leave split-K slabs at the start of `workspace` for the consumer)
+  // or SLM_W4_SILU_MUL (paired weights: c is [M, N/2] = silu(gate) * up).  Returns the number of
+  // fp32 slabs left in `workspace` (>= 2: c was NOT written) or 0 (c written as usual).
+  int forward_into(const torch::Tensor& a, torch::Tensor& c, int flags, const torch::Tensor& workspace) const;
+  // scratch bytes forward_into needs for M rows with these flags (0 = none)
+  size_t workspace_bytes(int64_t M, int flags) const;
+  bool paired() const { return paired_; }
 
   int64_t in_features() const { return k_src_; }
   int64_t out_features() const { return N_; }
@@ -140,6 +154,7 @@ class W4Linear {
   torch::Tensor wq_, sz_, perm_;
   int64_t K_ = 0, N_ = 0, group_size_ = 0;
   int64_t k_src_ = 0;  // width of the activations (== K_ unless the shard was padded)
+  bool paired_ = false;
   torch::ScalarType dtype_;
 };
 

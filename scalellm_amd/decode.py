@@ -534,6 +534,40 @@ class LlamaDecodeStep:
         return (best * vs + local).to(torch.int32)
 
 
+def hf_state_dict(step: "LlamaDecodeStep") -> dict:
+    """The tensors of a LlamaDecodeStep(keep_checkpoint=True) under their HuggingFace checkpoint names,
+    q / k / v and gate / up as SEPARATE tensors (what a Llama checkpoint holds and what the layer
+    classes fuse on load: llama.h:64-121, qkv_parallel_linear.cpp, multi_parallel_linear.cpp) --
+    the input of slm::LlamaForCausalLMHip::load_state_dict (csrc/shim/slm_llama_hip.h), so the C++
+    host step and this Python mirror can be built from one set of weights.  Single rank only."""
+    if step.ckpt is None or step.pa.world_size != 1:
+        raise ValueError("hf_state_dict needs LlamaDecodeStep(keep_checkpoint=True) on one rank")
+    s = step.shape
+    D = s.head_dim
+    nq, nkv, inter = s.n_heads * D, s.n_kv_heads * D, s.intermediate
+    sd = {"model.embed_tokens.weight": step.embed, "model.norm.weight": step.final_norm,
+          "lm_head.weight": step.lm_head.t()}   # [vocab, hidden] in a checkpoint
+
+    awq = step.layers[0]["qkv"].quant_args.quant_method == "awq"   # AWQ [K, N/8] / GPTQ [K/8, N]
+
+    def cols(ck, a, b):
+        out = {"qweight": ck["qweight"][:, a // 8:b // 8] if awq else ck["qweight"][:, a:b],
+               "qzeros": ck["qzeros"][:, a // 8:b // 8], "scales": ck["scales"][:, a:b]}
+        return {k: v.contiguous() for k, v in out.items()}
+    for i, ck in enumerate(step.ckpt):
+        pre = f"model.layers.{i}."
+        parts = {"self_attn.q_proj.": cols(ck["qkv"], 0, nq), "self_attn.k_proj.": cols(ck["qkv"], nq, nq + nkv),
+                 "self_attn.v_proj.": cols(ck["qkv"], nq + nkv, nq + 2 * nkv),
+                 "self_attn.o_proj.": ck["o"], "mlp.gate_proj.": cols(ck["gate_up"], 0, inter),
+                 "mlp.up_proj.": cols(ck["gate_up"], inter, 2 * inter), "mlp.down_proj.": ck["down"]}
+        for name, tensors in parts.items():
+            for k, v in tensors.items():
+                sd[pre + name + k] = v
+        sd[pre + "input_layernorm.weight"] = step.layers[i]["in_norm"]
+        sd[pre + "post_attention_layernorm.weight"] = step.layers[i]["post_norm"]
+    return sd
+
+
 def make_batch_inputs(q_lens, kv_lens, block_size: int, device, seed: int = 0, vocab: int = 128256):
     """Synthetic MIXED batch in the engine's input format (engine/batch.cpp:77-270): sequence i
     brings q_lens[i] new tokens (1 = decode, k + 1 = speculative verify, a chunk = chunked prefill)
