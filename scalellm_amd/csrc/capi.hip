@@ -18,7 +18,7 @@ const char* const kTuneNames[TUNE_COUNT] = {
     "SLM_W4_MT",            "SLM_W4_NTW",           "SLM_W4_PC",        "SLM_W4_SPLITK",
     "SLM_W4_POST",
     "SLM_W4_KS",            "SLM_W4_KS_CW",         "SLM_W4_KS_NW",     "SLM_W4_KS_TPW",
-    "SLM_W4_KS_DBG",
+    "SLM_W4_KS_DBG",        "SLM_W4_KS_MT2",
 };
 std::atomic<int32_t> g_tune[TUNE_COUNT];
 std::once_flag g_tune_once;

@@ -510,7 +510,7 @@ constexpr bool w4_pre_fits(int /*mt*/, int ntw, int ng, int pc) { return !(ntw =
 
 struct GemmPlan {
   int mt, ntw, ng, pc, post, small, gemv, split_k, chunks_per_split, n_mblocks, n_nblocks;
-  int ks, ks_cw, ks_nw, ks_tpw;  // K-sliced small-M kernel (w4_ks.hip)
+  int ks, ks_cw, ks_nw, ks_tpw, ks_mt;  // K-sliced small-M kernel (w4_ks.hip)
   size_t lds_bytes, part_bytes, aperm_bytes;
 };
 
@@ -665,6 +665,39 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
         pl->n_mblocks = 1;
         pl->n_nblocks = (n_tiles + tpw - 1) / tpw;
       }
+    }
+  }
+  pl->ks_mt = 1;
+  // 33 <= M <= 64 (round 4): the K-sliced stream with TWO row tiles -- every weight word unpacked once
+  // for two MFMAs.  One chunk of K per wave (the activations of both row tiles fill the registers), 8
+  // waves: a workgroup covers 1024 of K, the rest is split across workgroups (fp32 slabs, summed by
+  // the consumer under SLM_W4_DEFER_REDUCE or by the reduce kernel); about one workgroup per CU.
+  // Measured against the general kernel's BM = 64 tiles: profiles/r04_layer_msweep.jsonl.
+  // SLM_W4_KS_MT2=0 keeps the general kernel.
+  if (tune_get(TUNE_W4_KS, 1) != 0 && tune_get(TUNE_W4_KS_MT2, 1) != 0 && a->M > 32 && a->M <= 64 && !pl->gemv &&
+      a->K * a->N / 2 < ((int64_t)1 << 32) && (a->K / gs) * a->N * 4 < ((int64_t)1 << 32) &&
+      ((a->M - 1) * a->lda + a->K) * 2 < ((int64_t)1 << 31) &&
+      ((a->M - 1) * a->ldc + a->N) * 2 < ((int64_t)1 << 31) && a->M * a->N * 4 < ((int64_t)1 << 31) &&
+      gemm_ks_config_ok(pl->ng, 1, 8, 2)) {
+    const bool silu = (a->flags & SLM_W4_SILU_MUL) != 0;
+    const int n_tiles = (int)(a->N / 32);
+    const int ksplit = (n_chunks + 7) / 8;
+    const int forced_split = tune_get(TUNE_W4_SPLITK, 0);
+    int tpw = tune_get(TUNE_W4_KS_TPW, 0);
+    if (tpw <= 0) {
+      tpw = (int)(((int64_t)ksplit * n_tiles + 128) / 256);
+      if (tpw < 1) tpw = 1;
+    }
+    if (silu) tpw = (tpw + 1) & ~1;  // (gate, up) tile pairs stay in one workgroup
+    if (tpw > n_tiles) tpw = n_tiles;
+    if (ksplit <= 16 && (forced_split <= 0 || ksplit == forced_split)) {
+      pl->ks = 1;
+      pl->ks_mt = 2;
+      pl->ks_cw = 1; pl->ks_nw = 8; pl->ks_tpw = tpw;
+      pl->split_k = ksplit;
+      pl->chunks_per_split = 8;
+      pl->n_mblocks = 1;
+      pl->n_nblocks = (n_tiles + tpw - 1) / tpw;
     }
   }
   pl->part_bytes = pl->split_k > 1 ? (size_t)pl->split_k * a->M * a->N * sizeof(float) : 0;
@@ -887,7 +920,7 @@ static int gemm_impl(const slm_w4_gemm_args* a, const slm_w4_norm_prologue* np, 
   kp.ks_groups = (int)(a->K / a->group_size);
   kp.ks_dbg = tune_get(TUNE_W4_KS_DBG, 0);
   if (pl.ks)
-    launch_gemm_ks(kp, a->dtype, pl.ng, pl.ks_cw, pl.ks_nw, pl.n_nblocks * pl.split_k, st);
+    launch_gemm_ks(kp, a->dtype, pl.ng, pl.ks_cw, pl.ks_nw, pl.n_nblocks * pl.split_k, st, pl.ks_mt);
   else if (pl.gemv)
     launch_gemv(kp, a->dtype, pl.ng, st);
   else if (pl.small)

@@ -236,11 +236,12 @@ int gemv_global_splits(int64_t M, int64_t K, int64_t N, bool partials_ok);
 void launch_gemm_small(const GemmKParams& kp, int dtype, int ng, int n_blocks, hipStream_t st);
 constexpr size_t W4_SMALL_LDS_BYTES = 2 * 32 * 256;
 
-// K-sliced weight stream for M <= 32 (w4_ks.hip): NW waves x CW chunks of K per workgroup, the
-// activations of a wave's K slice live in its registers, partial tiles meet in LDS once per tile
+// K-sliced weight stream for M <= 32 (mt = 1) and 33 <= M <= 64 (mt = 2: two row tiles per unpacked
+// weight word) (w4_ks.hip): NW waves x CW chunks of K per workgroup, the activations of a wave's K
+// slice live in its registers, partial tiles meet in LDS once per tile
 void launch_gemm_ks(const GemmKParams& kp, int dtype, int ng, int cw, int nw, int n_blocks,
-                    hipStream_t st);
-bool gemm_ks_config_ok(int ng, int cw, int nw);
+                    hipStream_t st, int mt = 1);
+bool gemm_ks_config_ok(int ng, int cw, int nw, int mt = 1);
 constexpr size_t w4_ks_lds_bytes(int nw) { return (size_t)4 * nw * 4096 + 64; }  // 4 partial slots + counters
 
 // warp-specialised large-M kernel (w4_ws.hip): BM = 256, BN = 128, 512 threads

@@ -72,12 +72,21 @@ constexpr int KS_SLOTS = 4;  // partial-tile slots in LDS (see the slot arithmet
 
 // CW: 128-deep chunks of K per wave (1, 2, 4);  NG: scale groups per chunk (1: group >= 128,
 // 2: 64, 4: 32);  NW: waves per workgroup (4, 8);  TL: timeline probe (tools/probe_ks_timeline.py)
-template <typename T, int CW, int NG, int NW, bool TL = false, bool PK = false>
+// MT: 32-row tiles of tokens (1: M <= 32; 2: 33 <= M <= 64, round 4).  With MT = 2 every weight word is
+// unpacked ONCE and feeds two MFMAs (one per row tile): the stream that was VALU-issue-bound on the
+// unpack at M <= 32 (7 VALU + 1 MFMA per word) becomes 7 VALU + 2 MFMAs -- matrix-pipe-bound -- instead
+// of a second 55 us pass or the general kernel's 94-100 us (LDS fragment reads per MFMA, a barrier per
+// chunk).  The activations of both row tiles live in registers (64 VGPRs per chunk), which leaves room
+// for ONE chunk per wave: K is split over the 8 waves x ceil(K / 1024) workgroups (fp32 slabs, summed
+// by the consumer or the reduce kernel).  A 64 x 32 partial tile goes through the LDS meeting as two
+// consecutive entries of the slot sequence (2t, 2t + 1).
+template <typename T, int CW, int NG, int NW, bool TL = false, bool PK = false, int MT = 1>
 __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Mfma<T>::frag frag_t;
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   constexpr int RD = 8 / (2 * CW);   // column tiles per loop body (one turn of the 8-slot weight ring)
+  constexpr int VC = CW * MT;        // activation pieces staged per wave: (chunk, row tile), v = c * MT + mt
   constexpr int PP = 2;              // partial-sum tiles in flight (ping-pong under the epilogue)
   constexpr int NGW = CW * NG;       // scale segments per wave and tile
   constexpr int NP = (NGW + 1) / 2;  // segment pairs = fp32 MFMAs of the zero-point term
@@ -191,8 +200,8 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
   // needs no barrier.  DMA instruction i of a chunk moves rows 4i .. 4i+3: lane l -> row 4i + (l >> 4),
   // LDS position l & 15 holds the 16-B octet (l & 15) ^ (row & 15) (swizzle on the global side; the
   // fragment reads below are then conflict-free ds_read_b128).
-  frag_t act[CW][8];
-  float xa[NP];
+  frag_t act[MT][CW][8];
+  float xa[MT][NP];
   {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     // hand-made resource words for the asm DMA: base, base_hi (stride 0), bytes, flags
@@ -202,17 +211,21 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
     a_rs4.z = (uint32_t)(((p.M - 1) * p.lda + p.K) * 2); a_rs4.w = 0x00020000u;
     a_rs4.x = __builtin_amdgcn_readfirstlane(a_rs4.x); a_rs4.y = __builtin_amdgcn_readfirstlane(a_rs4.y);
     a_rs4.z = __builtin_amdgcn_readfirstlane(a_rs4.z); a_rs4.w = __builtin_amdgcn_readfirstlane(a_rs4.w);
-    uint32_t dma_voff[8];  // per-lane byte offset of DMA instruction i within a chunk column
+    uint32_t dma_voff[MT][8];  // per-lane byte offset of DMA instruction i within a chunk column
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = 4 * i + (lane >> 4);
-      const int rc = row < p.M ? row : (int)p.M - 1;  // rows >= M: clamped duplicates, never stored
-      dma_voff[i] = (uint32_t)(2 * rc * (int)p.lda + (((lane & 15) ^ (row & 15)) << 4));
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = 32 * mt + 4 * i + (lane >> 4);
+        const int rc = row < p.M ? row : (int)p.M - 1;  // rows >= M: clamped duplicates, never stored
+        dma_voff[mt][i] = (uint32_t)(2 * rc * (int)p.lda + (((lane & 15) ^ (row & 15)) << 4));
+      }
     }
     auto stage_base = [&](int b, int i) -> uint32_t {  // LDS byte address of DMA instruction i, buffer b
       return lds0 + (uint32_t)(((2 * b + (i >> 2)) * NW + wave) * 4096 + (i & 3) * 1024);
     };
-    auto dma_chunk = [&](int c) {
+    auto dma_chunk = [&](int v) {  // piece v = (chunk v / MT, row tile v % MT) into staging buffer v & 1
+      const int c = v / MT, mt = v % MT;
       const int cabs = cw0 + c;
       // chunks past K: out-of-range loads write zeros (zero activations x clamped weights = 0)
       const uint32_t a_soff = (cabs <= clast && !(p.ks_dbg & 1)) ? (uint32_t)cabs * 256u : KS_OOB;
@@ -221,10 +234,10 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
       // M <= 4 that is 1/8 of the activation traffic and of the LDS fill, the bulk of the prologue.
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        if (4 * i < p.M)
+        if (32 * mt + 4 * i < p.M)
           asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
                        :
-                       : "v"(dma_voff[i]), "s"(stage_base(c & 1, i)), "s"(a_rs4), "s"(a_soff)
+                       : "v"(dma_voff[mt][i]), "s"(stage_base(v & 1, i)), "s"(a_rs4), "s"(a_soff)
                        : "memory");
     };
     // fragment (row m = lane & 31, octet 2j + h) sits at row group m >> 2, row-in-group m & 3,
@@ -232,39 +245,43 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
     const int m = lane & 31;
     const uint32_t fr_lane = (uint32_t)((m >> 4) * NW * 4096 + ((m >> 2) & 3) * 1024 + (m & 3) * 256);
     const uint32_t fr_x = (uint32_t)(((m & 15) ^ (kh ? 1 : 0)) << 4);
-    auto frag_read = [&](int c, int j) -> frag_t {
-      const uint32_t off = (uint32_t)(((c & 1) * 2 * NW + wave) * 4096) + fr_lane + ((uint32_t)(32 * j) ^ fr_x);
+    auto frag_read = [&](int v, int j) -> frag_t {
+      const uint32_t off = (uint32_t)(((v & 1) * 2 * NW + wave) * 4096) + fr_lane + ((uint32_t)(32 * j) ^ fr_x);
       return __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(smem + off));
     };
     // activation sums per scale segment: v_dot2 of every packed pair against (1, 1) -- exact products,
     // fp32 accumulate -- then the two k halves of a row (lanes l and l + 32) are added; every lane ends
     // with X[m = lane & 31].  (32 VALU per chunk; eight MFMAs against a ones fragment cost twice the
     // issue time and serialise on the accumulator.)
-    float xg[2 * NP];
+    float xg[MT][2 * NP];
 #pragma unroll
-    for (int s2 = 0; s2 < 2 * NP; ++s2) xg[s2] = 0.f;
-    auto xsum_chunk = [&](int c) {
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2 * NP; ++s2) xg[mt][s2] = 0.f;
+    }
+    auto xsum_chunk = [&](int v) {
+      const int c = v / MT, mt = v % MT;
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         float xs0 = 0.f, xs1 = 0.f;
 #pragma unroll
         for (int jj = 0; jj < WPG; ++jj) {
-          const u32x4 f = __builtin_bit_cast(u32x4, act[c][g * WPG + jj]);
+          const u32x4 f = __builtin_bit_cast(u32x4, act[mt][c][g * WPG + jj]);
           xs0 = dot2<T>(f.x, KsOnes<T>::bits, xs0);
           xs1 = dot2<T>(f.y, KsOnes<T>::bits, xs1);
           xs0 = dot2<T>(f.z, KsOnes<T>::bits, xs0);
           xs1 = dot2<T>(f.w, KsOnes<T>::bits, xs1);
         }
         const float xs = xs0 + xs1;
-        xg[c * NG + g] = xs + __shfl_xor(xs, 32, 64);
+        xg[mt][c * NG + g] = xs + __shfl_xor(xs, 32, 64);
       }
     };
 #pragma unroll
-    for (int c0 = 0; c0 < CW; c0 += 2) {
+    for (int c0 = 0; c0 < VC; c0 += 2) {
       if (c0 > 0)  // the fragment reads of the previous pair have returned before their buffers are refilled
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       dma_chunk(c0);
-      if (c0 + 1 < CW) dma_chunk(c0 + 1);
+      if (c0 + 1 < VC) dma_chunk(c0 + 1);
       if (c0 > 0) {  // group sums of the previous pair run under this pair's DMA
         xsum_chunk(c0 - 2);
         xsum_chunk(c0 - 1);
@@ -290,24 +307,27 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
         }
       }
 #pragma unroll
-      for (int c = c0; c < c0 + 2 && c < CW; ++c) {
+      for (int v = c0; v < c0 + 2 && v < VC; ++v) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) act[c][j] = frag_read(c, j);
+        for (int j = 0; j < 8; ++j) act[v % MT][v / MT][j] = frag_read(v, j);
       }
     }
-    xsum_chunk(CW >= 2 ? CW - 2 : 0);
-    if (CW >= 2) xsum_chunk(CW - 1);
+    xsum_chunk(VC >= 2 ? VC - 2 : 0);
+    if (VC >= 2) xsum_chunk(VC - 1);
     // the partial-slot writes of tile 0 reuse the staging memory: the fragment reads are done (their
     // values fed the MFMAs above)
 #pragma unroll
-    for (int q = 0; q < NP; ++q) {
-      float x0 = xg[2 * q], x1 = xg[2 * q + 1];
-      asm volatile("" : "+v"(x0), "+v"(x1));  // values, not array slots: keeps the select off the stack
-      xa[q] = kh ? x1 : x0;  // A operand of the fp32 MFMA: k = lane >> 5 picks the segment of the pair
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        float x0 = xg[mt][2 * q], x1 = xg[mt][2 * q + 1];
+        asm volatile("" : "+v"(x0), "+v"(x1));  // values, not array slots: keeps the select off the stack
+        xa[mt][q] = kh ? x1 : x0;  // A operand of the fp32 MFMA: k = lane >> 5 picks the segment of the pair
+      }
     }
   }
 
-  if constexpr (TL) asm volatile("" : "+v"(xa[0]));
+  if constexpr (TL) asm volatile("" : "+v"(xa[0][0]));
   stamp(3);
   uint32_t magic_v = W4Magic<T>::bits;
   asm volatile("" : "+v"(magic_v));  // keep it in a VGPR (not re-materialised as a literal)
@@ -316,9 +336,12 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
 
   float* const red = reinterpret_cast<float*>(smem);
   const uint32_t cnt_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + CNT_OFF;
-  float hold[RPW];  // SLM_W4_SILU_MUL: the gate tile's values wait here for the up tile
+  float hold[MT][RPW];  // SLM_W4_SILU_MUL: the gate tile's values wait here for the up tile
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) hold[i] = 0.f;
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) hold[mt][i] = 0.f;
+  }
   const bool silu = p.silu != 0;
   const uint32_t ldc2 = (uint32_t)p.ldc * 2u, n4 = (uint32_t)p.N * 4u;
 
@@ -329,58 +352,60 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
   // t - 1: they are complete.  Three slots would not do (B may still be reducing t - 2).
   // `publish` (tile t, or nothing when acc_pub == nullptr) is issued between the partial reads and
   // the sums of tile tp: the reads go ahead of the 4 KiB of LDS writes instead of queueing behind them
+  // (MT = 2: column tile t is the entries t * MT and t * MT + 1 of the slot sequence -- its two row
+  // tiles; the argument above holds for the sequence whatever its entries are)
   auto reduce_store = [&](const int tp, const uint32_t braw, const int t_pub, const f32x16* acc_pub) {
     const bool live = tp >= 0 && tp < ntl;
-    const uint32_t target = tp >= 0 ? (uint32_t)(NW * ((tp >> 2) + 1)) : 0u;
-    const uint32_t caddr = cnt_lds + (uint32_t)((tp & 3) * 4);
-    uint32_t seen;
-    do {  // arrival check: by now (one tile later) it passes at the first look
-      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(caddr) : "memory");
-    } while (__builtin_amdgcn_readfirstlane(seen) < target);
-    stamp(6 + 4 * (tp < 0 ? 0 : tp));
-    const float* const theirs = red + (tp & 3) * SLOT_FLOATS + (wave * 64 + lane) * RPW;
-    f32x4 pv4[RPW == 4 ? NW : 1];
-    f32x2 pv2[RPW == 2 ? NW : 1];
 #pragma unroll
-    for (int src = 0; src < NW; ++src) {
-      if constexpr (RPW == 4) pv4[src] = *reinterpret_cast<const f32x4*>(theirs + src * 1024);
-      else pv2[src] = *reinterpret_cast<const f32x2*>(theirs + src * 1024);
+    for (int mt = 0; mt < MT; ++mt) {
+      const int sidx = tp * MT + mt;
+      const uint32_t target = tp >= 0 ? (uint32_t)(NW * ((sidx >> 2) + 1)) : 0u;
+      const uint32_t caddr = cnt_lds + (uint32_t)((sidx & 3) * 4);
+      uint32_t seen;
+      do {  // arrival check: by now (one tile later) it passes at the first look
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(caddr) : "memory");
+      } while (__builtin_amdgcn_readfirstlane(seen) < target);
+    }
+    stamp(6 + 4 * (tp < 0 ? 0 : tp));
+    f32x4 pv4[MT][RPW == 4 ? NW : 1];
+    f32x2 pv2[MT][RPW == 2 ? NW : 1];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const float* const theirs = red + ((tp * MT + mt) & 3) * SLOT_FLOATS + (wave * 64 + lane) * RPW;
+#pragma unroll
+      for (int src = 0; src < NW; ++src) {
+        if constexpr (RPW == 4) pv4[mt][src] = *reinterpret_cast<const f32x4*>(theirs + src * 1024);
+        else pv2[mt][src] = *reinterpret_cast<const f32x2*>(theirs + src * 1024);
+      }
     }
     if (acc_pub) {
-      // publish the partial tile: [slot][source wave][reducing wave][lane][RPW], then arrive
-      const f32x16& acc = *acc_pub;
-      float* const mine = red + (t_pub & 3) * SLOT_FLOATS + wave * 1024 + lane * RPW;
 #pragma unroll
-      for (int rg = 0; rg < NW; ++rg) {
-        if constexpr (RPW == 4) {
-          const f32x4 v = {acc[rg * 4], acc[rg * 4 + 1], acc[rg * 4 + 2], acc[rg * 4 + 3]};
-          *reinterpret_cast<f32x4*>(mine + rg * 256) = v;
-        } else {
-          const f32x2 v = {acc[rg * 2], acc[rg * 2 + 1]};
-          *reinterpret_cast<f32x2*>(mine + rg * 128) = v;
+      for (int mt = 0; mt < MT; ++mt) {
+        // publish the partial tile: [slot][source wave][reducing wave][lane][RPW], then arrive
+        const f32x16& acc = acc_pub[mt];
+        const int pidx = t_pub * MT + mt;
+        float* const mine = red + (pidx & 3) * SLOT_FLOATS + wave * 1024 + lane * RPW;
+#pragma unroll
+        for (int rg = 0; rg < NW; ++rg) {
+          if constexpr (RPW == 4) {
+            const f32x4 v = {acc[rg * 4], acc[rg * 4 + 1], acc[rg * 4 + 2], acc[rg * 4 + 3]};
+            *reinterpret_cast<f32x4*>(mine + rg * 256) = v;
+          } else {
+            const f32x2 v = {acc[rg * 2], acc[rg * 2 + 1]};
+            *reinterpret_cast<f32x2*>(mine + rg * 128) = v;
+          }
         }
+        // one lane adds 1 to the tile's counter; DS operations of a wave execute in issue order, so
+        // whoever sees the count also sees the partial tile
+        const uint32_t paddr = cnt_lds + (uint32_t)((pidx & 3) * 4);
+        const uint32_t one = 1u;
+        uint64_t ex;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
+                     : "=&s"(ex)
+                     : "v"(paddr), "v"(one)
+                     : "memory");
       }
-      // one lane adds 1 to the tile's counter; DS operations of a wave execute in issue order, so
-      // whoever sees the count also sees the partial tile
-      const uint32_t paddr = cnt_lds + (uint32_t)((t_pub & 3) * 4);
-      const uint32_t one = 1u;
-      uint64_t ex;
-      asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
-                   : "=&s"(ex)
-                   : "v"(paddr), "v"(one)
-                   : "memory");
       stamp(5 + 4 * t_pub);
-    }
-    float sum[RPW];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) sum[i] = 0.f;
-#pragma unroll
-    for (int src = 0; src < NW; ++src) {  // fixed order: bit-reproducible
-      if constexpr (RPW == 4) {
-        sum[0] += pv4[src].x; sum[1] += pv4[src].y; sum[2] += pv4[src].z; sum[3] += pv4[src].w;
-      } else {
-        sum[0] += pv2[src].x; sum[1] += pv2[src].y;
-      }
     }
     // store (straight-line: disabled stores go out of range and are dropped).  C/D layout of the
     // 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -391,20 +416,34 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
     const bool part_on = live && !final_out;
     const float bv = has_bias ? lo_f32<T>(braw) : 0.f;
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-      const int r = wave * RPW + i;
-      const uint32_t row = (uint32_t)((r & 3) + 8 * (r >> 2)) + (kh ? 4u : 0u);
-      const float v = sum[i] + bv;
-      float o = v;
-      if (silu) o = silu_mul_acc<T>(hold[i], v);  // wave-uniform branch, VALU only: vmcnt bookkeeping unaffected
-      hold[i] = v;
-      const uint16_t o16 = pack1<T>(o);
-      __builtin_amdgcn_raw_buffer_store_b16(o16, c_rs, (int)(c_on ? row * ldc2 + ocol * 2u : KS_OOB), 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, sum[i]), part_rs,
-                                            (int)(part_on ? row * n4 + col * 4u : KS_OOB), 0, 0);
+    for (int mt = 0; mt < MT; ++mt) {
+      float sum[RPW];
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) sum[i] = 0.f;
+#pragma unroll
+      for (int src = 0; src < NW; ++src) {  // fixed order: bit-reproducible
+        if constexpr (RPW == 4) {
+          sum[0] += pv4[mt][src].x; sum[1] += pv4[mt][src].y; sum[2] += pv4[mt][src].z; sum[3] += pv4[mt][src].w;
+        } else {
+          sum[0] += pv2[mt][src].x; sum[1] += pv2[mt][src].y;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int r = wave * RPW + i;
+        const uint32_t row = (uint32_t)(32 * mt + (r & 3) + 8 * (r >> 2)) + (kh ? 4u : 0u);
+        const float v = sum[i] + bv;
+        float o = v;
+        if (silu) o = silu_mul_acc<T>(hold[mt][i], v);  // wave-uniform branch, VALU only: vmcnt bookkeeping unaffected
+        hold[mt][i] = v;
+        const uint16_t o16 = pack1<T>(o);
+        __builtin_amdgcn_raw_buffer_store_b16(o16, c_rs, (int)(c_on ? row * ldc2 + ocol * 2u : KS_OOB), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, sum[i]), part_rs,
+                                              (int)(part_on ? row * n4 + col * 4u : KS_OOB), 0, 0);
+      }
     }
     if constexpr (TL) {
-      float keep = hold[0];
+      float keep = hold[0][0];
       asm volatile("" : "+v"(keep));
       stamp(7 + 4 * (tp < 0 ? 0 : tp));
     }
@@ -422,9 +461,12 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
       // tile t + RD right away: issued BEFORE this tile's weight refills, so waiting for them at the
       // start of tile t + RD leaves a full ring of weight loads in flight
       float sc[NGW];
-      f32x16 acc;
+      f32x16 acc[MT];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+      }
 #pragma unroll
       for (int q = 0; q < NP; ++q) {
         float cz2[2] = {0.f, 0.f};
@@ -441,7 +483,10 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
         float c0 = cz2[0], c1 = cz2[1];
         asm volatile("" : "+v"(c0), "+v"(c1));  // values, not array slots: keeps the select off the stack
         // zero-point term on the matrix pipe (exact fp32): acc = sum_seg X_seg[m] * (-(magic+z) s)[n]
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[q], kh ? c1 : c0, acc, 0, 0, 0);
+        const float cz = kh ? c1 : c0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[mt][q], cz, acc[mt], 0, 0, 0);
       }
       const uint32_t braw = bsr[d];
       __builtin_amdgcn_sched_barrier(0);
@@ -455,7 +500,7 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
 
       // ---- the weight stream of this tile.  Segment s accumulates in tmp[s & 1] while the scale
       // epilogue of segment s - 1 runs under its MFMAs: exactly two partial tiles are live
-      f32x16 tmp[PP];
+      f32x16 tmp[MT][PP];
 #pragma unroll
       for (int s2 = 0; s2 < NGW; ++s2) {
         const int c = s2 / NG, g = s2 % NG;
@@ -474,13 +519,17 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
           }
           const u32x4 packed = {o[0], o[1], o[2], o[3]};
           const frag_t bf = __builtin_bit_cast(frag_t, packed);
-          if (jj == 0) {
-            f32x16 z;
+          // ONE unpack, MT MFMAs: the same B fragment against each row tile's activations
 #pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = 0.f;
-            tmp[s2 % PP] = Mfma<T>::run(act[c][j], bf, z);
-          } else {
-            tmp[s2 % PP] = Mfma<T>::run(act[c][j], bf, tmp[s2 % PP]);
+          for (int mt = 0; mt < MT; ++mt) {
+            if (jj == 0) {
+              f32x16 z;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) z[r] = 0.f;
+              tmp[mt][s2 % PP] = Mfma<T>::run(act[mt][c][j], bf, z);
+            } else {
+              tmp[mt][s2 % PP] = Mfma<T>::run(act[mt][c][j], bf, tmp[mt][s2 % PP]);
+            }
           }
           if (s2 > 0 && jj == (WPG > 1 ? 1 : 0)) {
             const float sv = sc[s2 - 1];
@@ -488,14 +537,17 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
               const f32x2 sv2 = {sv, sv};
 #pragma unroll
               for (int r = 0; r < 16; r += 2) {
-                f32x2 a2 = {acc[r], acc[r + 1]};
-                const f32x2 t2 = {tmp[(s2 - 1) % PP][r], tmp[(s2 - 1) % PP][r + 1]};
+                f32x2 a2 = {acc[0][r], acc[0][r + 1]};
+                const f32x2 t2 = {tmp[0][(s2 - 1) % PP][r], tmp[0][(s2 - 1) % PP][r + 1]};
                 a2 = __builtin_elementwise_fma(sv2, t2, a2);
-                acc[r] = a2.x; acc[r + 1] = a2.y;
+                acc[0][r] = a2.x; acc[0][r + 1] = a2.y;
               }
             } else {
 #pragma unroll
-              for (int r = 0; r < 16; ++r) acc[r] = fmaf(sv, tmp[(s2 - 1) % PP][r], acc[r]);
+              for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][r] = fmaf(sv, tmp[mt][(s2 - 1) % PP][r], acc[mt][r]);
+              }
             }
             // pin the epilogue HERE (under this segment's MFMAs): without an anchor the scheduler
             // sinks all of a tile's epilogues to the tile end and keeps every partial tile live.
@@ -503,7 +555,10 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
             if (jj + 1 < WPG || s2 + 1 < NGW) {
               const int jn = jj + 1 < WPG ? j + 1 : ((s2 + 1) % NG) * WPG;
               const int cn = jj + 1 < WPG ? c : (s2 + 1) / NG;
-              asm volatile("" : "+v"(acc), "+v"(ring[d][cn][jn >> 2]));
+              if constexpr (MT == 2)
+                asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(ring[d][cn][jn >> 2]));
+              else
+                asm volatile("" : "+v"(acc[0]), "+v"(ring[d][cn][jn >> 2]));
             }
           }
           if ((j & 3) == 3) {  // last word of ring slot (c, j >> 2): refill it for tile t + RD
@@ -518,24 +573,34 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
             const f32x2 sv2 = {sv, sv};
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-              f32x2 a2 = {acc[r], acc[r + 1]};
-              const f32x2 t2 = {tmp[s2 % PP][r], tmp[s2 % PP][r + 1]};
+              f32x2 a2 = {acc[0][r], acc[0][r + 1]};
+              const f32x2 t2 = {tmp[0][s2 % PP][r], tmp[0][s2 % PP][r + 1]};
               a2 = __builtin_elementwise_fma(sv2, t2, a2);
-              acc[r] = a2.x; acc[r + 1] = a2.y;
+              acc[0][r] = a2.x; acc[0][r + 1] = a2.y;
             }
           } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = fmaf(sv, tmp[s2 % PP][r], acc[r]);
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[mt][r] = fmaf(sv, tmp[mt][s2 % PP][r], acc[mt][r]);
+            }
           }
         }
       }
 
       // ---- publish this tile; one tile later: sum and store the previous one
-      reduce_store(t - 1, bprev, t, &acc);
+      reduce_store(t - 1, bprev, t, acc);
       bprev = braw;
     }
   } while (++it < n_iter);
   reduce_store(n_iter * RD - 1, bprev, 0, nullptr);
+}
+
+// 33 <= M <= 64: two row tiles, one chunk per wave, 8 waves (the register budget: see the kernel header)
+template <typename T, int NG>
+static void launch_ks_mt2(const GemmKParams& kp, int n_blocks, hipStream_t st) {
+  hipLaunchKernelGGL((w4a16_gemm_ks_kernel<T, 1, NG, 8, false, false, 2>), dim3((unsigned)n_blocks), dim3(512),
+                     w4_ks_lds_bytes(8), st, kp);
 }
 
 template <typename T, int CW, int NG, int NW>
@@ -569,7 +634,11 @@ static void launch_ks_cw(const GemmKParams& kp, int ng, int cw, int nw, int n_bl
   else launch_ks_ng<T, 1>(kp, ng, nw, n_blocks, st);
 }
 
-bool gemm_ks_config_ok(int ng, int cw, int nw) {
+bool gemm_ks_config_ok(int ng, int cw, int nw, int mt) {
+  // two row tiles: group >= 128 only -- the NG = 2 / 4 instantiations spill (1 / 15 VGPRs at the 256 cap)
+  // and are neither planned nor built
+  if (mt == 2) return cw == 1 && nw == 8 && ng == 1;
+  if (mt != 1) return false;
   if (cw != 1 && cw != 2 && cw != 4) return false;
   if (nw != 4 && nw != 8) return false;
   if (ng == 4 && cw == 4) return false;  // 16 segments per wave: register budget
@@ -578,7 +647,12 @@ bool gemm_ks_config_ok(int ng, int cw, int nw) {
 }
 
 void launch_gemm_ks(const GemmKParams& kp, int dtype, int ng, int cw, int nw, int n_blocks,
-                    hipStream_t st) {
+                    hipStream_t st, int mt) {
+  if (mt == 2) {  // (ng == 1: gemm_ks_config_ok)
+    if (dtype == SLM_BF16) launch_ks_mt2<bf16_tag, 1>(kp, n_blocks, st);
+    else launch_ks_mt2<f16_tag, 1>(kp, n_blocks, st);
+    return;
+  }
   if ((kp.ks_dbg & 8) && !(kp.ks_dbg & 4) && dtype == SLM_BF16 && ng == 1 && nw == 8 && cw == 4) {  // packed-fma probe
     hipLaunchKernelGGL((w4a16_gemm_ks_kernel<bf16_tag, 4, 1, 8, false, true>), dim3((unsigned)n_blocks), dim3(512),
                        w4_ks_lds_bytes(8), st, kp);

@@ -288,6 +288,38 @@ def test_k_sliced_small_m_kernel_grid(bits):
         assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, knobs, err)
 
 
+@pytest.mark.parametrize("bits", ["bf16", "f16"])
+def test_two_row_tile_k_sliced_kernel_grid(bits):
+    """33 <= M <= 64 on the K-sliced stream with TWO row tiles (w4_ks.hip, MT = 2, round 4: every weight
+    word unpacked once for two MFMAs; one chunk of K per wave, K split over 8 waves x ceil(K / 1024)
+    workgroups): the Llama-3-8B layer shapes, K that does not fill the last workgroup's waves, tile
+    runs that do not divide N, rows beyond M never stored (M = 33: one live row in the second tile),
+    per-channel and wide groups, both formats, act-order, bias -- against the oracle, and against the
+    general kernel's BM = 64 tiles on the same inputs (SLM_W4_KS_MT2=0) to GEMM rounding."""
+    from scalellm_amd import kernels
+    i = 0
+    for M, N, K, gs, fmt, act, knobs in (
+            (64, 4096, 4096, 128, "awq", False, {}),                      # o_proj: 4 workgroups over K
+            (33, 6144, 4096, 128, "awq", False, {}),                      # qkv, one row in the second tile
+            (48, 1024, 14336, 128, "awq", False, {}),                     # down_proj depth: 14 slabs
+            (64, 28672, 4096, 128, "awq", False, {}),                     # gate_up width
+            (40, 1024, 1152, 128, "gptq", False, {}),                     # 9 chunks: 7 idle waves in slab 2
+            (64, 480, 1024, 128, "gptq", False, dict(SLM_W4_KS_TPW=4)),   # 15 tiles in runs of 4
+            (50, 384, 2048, -1, "gptq", False, {}),                       # per-channel scales
+            (57, 224, 1792, 256, "gptq", False, dict(SLM_W4_KS_TPW=2)),   # group wider than a wave's chunk
+            (64, 2048, 2048, 128, "gptq", True, {}),                      # act-order column gather
+            (34, 96, 128, 128, "awq", False, {})):                        # one chunk: 7 idle waves
+        i += 1
+        case = helpers.make_quant_case(2700 + i, K, N, gs, fmt, bits, act_order=act)
+        with kernels.tuning(**knobs):
+            out, ref = _run_gemm(case, bits, M, bias=(i % 2 == 1), seed=i)
+        err = _rel_err(out, ref)
+        assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, knobs, err)
+        with kernels.tuning(SLM_W4_KS_MT2=0):
+            base, _ = _run_gemm(case, bits, M, bias=(i % 2 == 1), seed=i)
+        assert _rel_err(out, base) < GEMM_TOL[bits] / 2, (M, N, K, "vs the general kernel")
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_seeded_fuzz_over_shapes_and_batch_sizes(seed):
     """A seeded random walk over what the plan switches on -- M across every kernel regime (GEMV, K-sliced,
@@ -386,7 +418,7 @@ def test_repeated_launches_are_bit_identical(M, K, N, env, tune):
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("M,K,N", [(256, 4096, 4096), (256, 14336, 4096), (32, 4096, 4096),
-                                   (32, 14336, 4096), (7, 4096, 1024)])
+                                   (32, 14336, 4096), (7, 4096, 1024), (64, 4096, 4096), (48, 14336, 4096)])
 def test_deferred_splitk_reduce_into_rms_norm(M, K, N, dtype):
     """SLM_W4_DEFER_REDUCE: a split-K GEMM leaves its fp32 slabs in the workspace and
     slm_rms_norm_splitk sums them itself -- same order and rounding as the reduce kernel, so
@@ -408,7 +440,7 @@ def test_deferred_splitk_reduce_into_rms_norm(M, K, N, dtype):
     out, res = torch.empty_like(c), res0.clone()
     kernels.rms_norm(out, c2, w, 1e-5, res, partials=h)
     torch.cuda.synchronize()
-    if (M, K, N) in ((256, 14336, 4096), (32, 14336, 4096)):
+    if (M, K, N) in ((256, 14336, 4096), (32, 14336, 4096), (64, 4096, 4096), (48, 14336, 4096)):
         assert int(h) >= 2, "the down-projection shapes are split over K"
     if not h:
         assert torch.equal(c2, c)
