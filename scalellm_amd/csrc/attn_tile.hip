@@ -46,7 +46,7 @@ struct TileMfma<f16_tag> {
   }
 };
 
-constexpr int TILE_KV = 32;
+// KV rows per tile: 32 (one S^T block per wave and tile) or 64 (two: KVT template parameter)
 // V tile in LDS: HD/16 sub-tiles of [32 kv][16 d] bf16 (32 B per kv row, 1 KiB per sub-tile), the
 // image ds_read_b64_tr_b16 gathers from: a 16-lane group reads a [4 kv][16 d] block (lane t points
 // at kv row t/4, 8-byte chunk t%4) and lane t receives the 4 kv values of column t.  Sub-tile s
@@ -67,15 +67,26 @@ typedef __attribute__((address_space(3))) tr_v4s tr_lds_v4s;
 // the causal diagonal of every row of the wave then skip the whole mask / bias arithmetic
 // (scale + max only) -- left generic, the compiler if-converts the feature tests into straight-line
 // code (16 tanh + 16 int->float + 5 compare/select per score, ~2/3 of the loop's VALU work).
-template <typename T, int HD, int NW, bool PF, bool PLAIN>
+// KVT / DB (round 4, the prefill classes): KV tiles of 64 rows -- two S^T blocks per wave and tile, so
+// half the barriers, table lookups and loop overhead per KV row -- in a DOUBLE-BUFFERED LDS image: the
+// next tile's registers are stored into the other buffer right after this tile's MFMAs, ONE barrier per
+// tile (the single-buffer form needs "everybody done reading" + "everybody done writing").
+template <typename T, int HD, int NW, bool PF, bool PLAIN, int KVT = 32, bool DB = false>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) attn_tile_kernel(const AttnKParams p, int tiles_per_seq) {
   typedef typename TileMfma<T>::frag frag_t;
+  static_assert(KVT == 32 || KVT == 64, "KV tile rows");
+  static_assert(!DB || PF, "the double-buffered form prefetches through registers");
+  constexpr int TILE_KV = KVT;
+  constexpr int NH = KVT / 32;        // 32-row S^T blocks per tile
   constexpr int KSTEPS = HD / 16;     // MFMA k-steps of the QK product
   constexpr int DT = HD / 32;         // 32-row d-tiles of the output
   constexpr int NSLOT = HD / 8;       // 16-B slots per K row
   constexpr int K_BYTES = TILE_KV * HD * 2;
-  __shared__ __attribute__((aligned(16))) char k_lds[K_BYTES];
-  __shared__ __attribute__((aligned(16))) char v_lds[(HD / 16) * V_SUB_STRIDE];
+  constexpr int VH_BYTES = (HD / 16) * V_SUB_STRIDE;  // V image of one 32-row half tile
+  constexpr int V_BYTES = NH * VH_BYTES;
+  constexpr int NBUF = DB ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) char k_lds[NBUF * K_BYTES];
+  __shared__ __attribute__((aligned(16))) char v_lds[NBUF * V_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -239,14 +250,15 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
     }
     if constexpr (AHEAD) slot_load(kt_next);
   };
-  auto tile_store = [&]() {
+  auto tile_store = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
       const int idx = tid + nthreads * i;
       const int r = idx / NSLOT, sl = idx % NSLOT;
-      *reinterpret_cast<u32x4*>(k_lds + r * (HD * 2) + ((sl ^ (r & (NSLOT - 1))) << 4)) = kreg[i];
-      // V: row-major sub-tiles (slot sl = d / 8 -> sub-tile sl / 2, half sl % 2)
-      *reinterpret_cast<u32x4*>(v_lds + v_sub_base(sl >> 1) + r * 32 + ((sl & 1) << 4)) = vreg[i];
+      *reinterpret_cast<u32x4*>(k_lds + buf * K_BYTES + r * (HD * 2) + ((sl ^ (r & (NSLOT - 1))) << 4)) = kreg[i];
+      // V: row-major sub-tiles (slot sl = d / 8 -> sub-tile sl / 2, half sl % 2), one image per 32 rows
+      *reinterpret_cast<u32x4*>(v_lds + buf * V_BYTES + (r >> 5) * VH_BYTES + v_sub_base(sl >> 1) + (r & 31) * 32 +
+                                ((sl & 1) << 4)) = vreg[i];
     }
   };
   // transpose-read address of this lane inside a sub-tile pair: lanes 16..31 / 48..63 read the odd
@@ -259,10 +271,11 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
     if (wg_lo < wg_hi_s) {
       slot_load(wg_lo);
       tile_load(min(wg_lo + TILE_KV, wg_hi_s - 1));
-      tile_store();
+      tile_store(0);
     }
     __syncthreads();
   }
+  int cur = 0;  // LDS buffer holding the tile being consumed (DB)
   for (int kt0 = wg_lo; kt0 < wg_hi_s; kt0 += TILE_KV) {
     if constexpr (PF) {
       // next tile's rows travel HBM -> registers while this tile is consumed from LDS
@@ -272,39 +285,51 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
       __syncthreads();  // previous tile fully consumed
       slot_load(kt0);
       tile_load(kt0);
-      tile_store();
+      tile_store(0);
       __syncthreads();
     }
+    const char* const kb = k_lds + (DB ? cur * K_BYTES : 0);
 
-    // ---- S^T = K . Q^T ----
-    f32x16 sacc;
+    // ---- S^T = K . Q^T : NH blocks of 32 kv rows ----
+    f32x16 sacc[NH];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    for (int h = 0; h < NH; ++h) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[h][r] = 0.f;
+    }
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
       const int sl = 2 * s + hh;
-      const u32x4 kv4 = *reinterpret_cast<const u32x4*>(k_lds + l31 * (HD * 2) +
-                                                        ((sl ^ (l31 & (NSLOT - 1))) << 4));
-      sacc = TileMfma<T>::run(__builtin_bit_cast(frag_t, kv4), qf[s], sacc);
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int kr = 32 * h + l31;
+        const u32x4 kv4 = *reinterpret_cast<const u32x4*>(kb + kr * (HD * 2) + ((sl ^ (kr & (NSLOT - 1))) << 4));
+        sacc[h] = TileMfma<T>::run(__builtin_bit_cast(frag_t, kv4), qf[s], sacc[h]);
+      }
     }
 
     // ---- scale, soft-cap, alibi, mask; online softmax for this lane's query row ----
-    float sv[16];
+    // The scores stay in the accumulator registers: masked tiles rewrite them in place (scaled, biased,
+    // -inf where invisible) and exponentiate with multiplier 1; interior tiles (no mask, no bias) leave
+    // the RAW scores, take the row max on them (pairs -> v_max3_f32) and let the scale ride in the
+    // exponent's fma (sm_scale > 0: checked by `interior`).
     float mloc = -INFINITY;
     // wave-uniform: the smallest diagonal of the wave's rows is that of its first row
-    const bool interior = PLAIN && kt0 + TILE_KV <= kv_len &&
+    const bool interior = PLAIN && p.scale_log2 > 0.f && kt0 + TILE_KV <= kv_len &&
                           kt0 + TILE_KV - 1 <= kv_len - q_len + (row0 + wave * 32) / G;
+    float cmul = 1.0f;
     if (interior) {
+      float mraw = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        sv[r] = sacc[r] * p.scale_log2;
-        mloc = fmaxf(mloc, sv[r]);
-      }
+      for (int r = 0; r < 16 * NH; r += 2)
+        mraw = fmaxf(fmaxf(mraw, sacc[r >> 4][r & 15]), sacc[(r + 1) >> 4][(r + 1) & 15]);
+      mloc = mraw * p.scale_log2;
+      cmul = p.scale_log2;
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kv_idx = kt0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        float a = sacc[r];
+      for (int r = 0; r < 16 * NH; ++r) {
+        const int kv_idx = kt0 + 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * hh;
+        float a = sacc[r >> 4][r & 15];
         if constexpr (!PLAIN) {
           if (p.softcap > 0.f) a = fast_tanh(a * p.pre_scale);
           a = a * p.scale_log2 + slope2 * (float)kv_idx;
@@ -316,7 +341,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
           if (p.window >= 0) vis = vis && (diag - kv_idx) <= p.window;
         }
         a = vis ? a : -INFINITY;
-        sv[r] = a;
+        sacc[r >> 4][r & 15] = a;
         mloc = fmaxf(mloc, a);
       }
     }
@@ -338,9 +363,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
         for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
     }
     float lsum = 0.f;
+    float sv[16 * NH];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      sv[r] = fast_exp2(sv[r] - m_run);
+    for (int r = 0; r < 16 * NH; ++r) {
+      sv[r] = fast_exp2(fmaf(sacc[r >> 4][r & 15], cmul, -m_run));
       lsum += sv[r];
     }
     lsum += __shfl_xor(lsum, 32, 64);
@@ -348,7 +374,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
 
     // ---- O^T += V^T . P^T : P fragments straight from the softmax registers ----
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
+    for (int s2 = 0; s2 < 2 * NH; ++s2) {
       u32x4 pb;
       pb.x = pack2<T>(sv[8 * s2 + 0], sv[8 * s2 + 1]);
       pb.y = pack2<T>(sv[8 * s2 + 2], sv[8 * s2 + 3]);
@@ -360,7 +386,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
         // A[i = d row][k]: kv = 16*s2 + 4*hh + e (e < 4), 16*s2 + 8 + 4*hh + (e - 4): the order the
         // softmax registers hold P in
         // (sub-tile 2d+1 is always v_sub_base(1) - v_sub_base(0) past sub-tile 2d: folded into v_lane)
-        const uintptr_t va0 = v_lane + (uint32_t)(v_sub_base(2 * d) + (16 * s2) * 32);
+        const uintptr_t va0 = v_lane + (uint32_t)(v_sub_base(2 * d) + (16 * (s2 & 1)) * 32 + (s2 >> 1) * VH_BYTES +
+                                                  (DB ? cur * V_BYTES : 0));
         const tr_v4s t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds_v4s*)va0);
         const tr_v4s t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds_v4s*)(va0 + 8 * 32));
         const u32x2 v0 = __builtin_bit_cast(u32x2, t0), v1 = __builtin_bit_cast(u32x2, t1);
@@ -368,9 +395,15 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
         oacc[d] = TileMfma<T>::run(__builtin_bit_cast(frag_t, va), pfrag, oacc[d]);
       }
     }
-    if constexpr (PF) {
+    if constexpr (DB) {
+      // the other buffer was last read one tile ago and every wave has passed the barrier since:
+      // store the prefetched tile there right away; ONE barrier publishes it and retires this tile
+      tile_store(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    } else if constexpr (PF) {
       __syncthreads();  // every wave is done reading this tile
-      tile_store();
+      tile_store(0);
       __syncthreads();
     }
   }
@@ -423,7 +456,8 @@ int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t rows, hipStream_t
   const int64_t grid = tiles_per_seq * kp.n_kv_heads * kp.batch * kp.n_splits;
   if (grid <= 0 || grid > 0x7fffffffLL) return SLM_ERR_UNSUPPORTED;
   const dim3 g((unsigned)grid), blk(64 * nw);
-  const bool pf = tune_get(TUNE_ATTN_TILE_PF, 1) != 0;
+  const int pf_mode = tune_get(TUNE_ATTN_TILE_PF, 1);
+  const bool pf = pf_mode != 0;
   const bool plain = kp.softcap <= 0.f && kp.alibi == nullptr && kp.window < 0;
 #define SLM_TILE(TT, HDD, NWW)                                                                    \
   do {                                                                                            \
@@ -431,16 +465,38 @@ int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t rows, hipStream_t
     else if (pf) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, false>), g, blk, 0, st, kp, (int)tiles_per_seq); \
     else hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, false, false>), g, blk, 0, st, kp, (int)tiles_per_seq); \
   } while (0)
-#define SLM_TILE_NW(TT, HDD)                                                                      \
+  // the prefill classes (2 / 4 waves): 64-row KV tiles, double-buffered (SLM_ATTN_TILE_PF=2 keeps the
+  // 32-row single-buffer form for A/B runs)
+#define SLM_TILE64(TT, HDD, NWW)                                                                  \
   do {                                                                                            \
-    if (nw == 1) SLM_TILE(TT, HDD, 1); else if (nw == 2) SLM_TILE(TT, HDD, 2); else SLM_TILE(TT, HDD, 4); \
+    if (plain) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, true, 64, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
+    else hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, false, 64, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
+  } while (0)
+  // 64-row tiles where the instantiation keeps two waves per SIMD (no AGPR overflow): head_dim 128 with 4
+  // waves, head_dim 64 with 2 or 4 (head_dim 128 x 2 waves stages 8 + 8 rows of K / V per thread and
+  // lands at 254 VGPRs + 104 AGPRs = one wave per SIMD: it keeps the 32-row form)
+#define SLM_TILE_NW128(TT)                                                                        \
+  do {                                                                                            \
+    if (nw == 1) SLM_TILE(TT, 128, 1);                                                            \
+    else if (nw == 2) SLM_TILE(TT, 128, 2);                                                       \
+    else if (pf_mode == 1) SLM_TILE64(TT, 128, 4);                                                \
+    else SLM_TILE(TT, 128, 4);                                                                    \
+  } while (0)
+#define SLM_TILE_NW64(TT)                                                                         \
+  do {                                                                                            \
+    if (nw == 1) SLM_TILE(TT, 64, 1);                                                             \
+    else if (pf_mode == 1 && nw == 2) SLM_TILE64(TT, 64, 2);                                      \
+    else if (pf_mode == 1) SLM_TILE64(TT, 64, 4);                                                 \
+    else if (nw == 2) SLM_TILE(TT, 64, 2); else SLM_TILE(TT, 64, 4);                              \
   } while (0)
   if (dtype == SLM_BF16) {
-    if (kp.head_dim == 128) SLM_TILE_NW(bf16_tag, 128); else SLM_TILE_NW(bf16_tag, 64);
+    if (kp.head_dim == 128) SLM_TILE_NW128(bf16_tag); else SLM_TILE_NW64(bf16_tag);
   } else {
-    if (kp.head_dim == 128) SLM_TILE_NW(f16_tag, 128); else SLM_TILE_NW(f16_tag, 64);
+    if (kp.head_dim == 128) SLM_TILE_NW128(f16_tag); else SLM_TILE_NW64(f16_tag);
   }
-#undef SLM_TILE_NW
+#undef SLM_TILE_NW128
+#undef SLM_TILE_NW64
+#undef SLM_TILE64
 #undef SLM_TILE
   return hip_check_launch();
 }

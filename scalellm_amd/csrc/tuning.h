@@ -34,7 +34,7 @@ enum TuneKey : int {
   TUNE_W4_KS_NW,          // SLM_W4_KS_NW          forced waves per workgroup (4/8/16)
   TUNE_W4_KS_TPW,         // SLM_W4_KS_TPW         forced column tiles per workgroup
   TUNE_W4_KS_DBG,         // SLM_W4_KS_DBG         probe bits (1 = no activation loads, 2 = no weight loads): WRONG results
-  TUNE_W4_KS_MT2,         // SLM_W4_KS_MT2         0 = 33 <= M <= 64 stays on the general kernel (no two-row-tile K-sliced stream)
+  TUNE_W4_KS_MT2,         // SLM_W4_KS_MT2         1 = 33 <= M <= 64 on the two-row-tile K-sliced stream (K <= 4096), 2 = any K; default 0
   TUNE_COUNT
 };
 

@@ -295,13 +295,13 @@ def test_two_row_tile_k_sliced_kernel_grid(bits):
     workgroups): the Llama-3-8B layer shapes, K that does not fill the last workgroup's waves, tile
     runs that do not divide N, rows beyond M never stored (M = 33: one live row in the second tile),
     per-channel and wide groups, both formats, act-order, bias -- against the oracle, and against the
-    general kernel's BM = 64 tiles on the same inputs (SLM_W4_KS_MT2=0) to GEMM rounding."""
+    general kernel's BM = 64 tiles on the same inputs (the default plan) to GEMM rounding."""
     from scalellm_amd import kernels
     i = 0
     for M, N, K, gs, fmt, act, knobs in (
             (64, 4096, 4096, 128, "awq", False, {}),                      # o_proj: 4 workgroups over K
             (33, 6144, 4096, 128, "awq", False, {}),                      # qkv, one row in the second tile
-            (48, 1024, 14336, 128, "awq", False, {}),                     # down_proj depth: 14 slabs
+            (48, 1024, 14336, 128, "awq", False, dict(SLM_W4_KS_MT2=2)),  # down_proj depth: 14 slabs (not the default plan)
             (64, 28672, 4096, 128, "awq", False, {}),                     # gate_up width
             (40, 1024, 1152, 128, "gptq", False, {}),                     # 9 chunks: 7 idle waves in slab 2
             (64, 480, 1024, 128, "gptq", False, dict(SLM_W4_KS_TPW=4)),   # 15 tiles in runs of 4
@@ -311,7 +311,7 @@ def test_two_row_tile_k_sliced_kernel_grid(bits):
             (34, 96, 128, 128, "awq", False, {})):                        # one chunk: 7 idle waves
         i += 1
         case = helpers.make_quant_case(2700 + i, K, N, gs, fmt, bits, act_order=act)
-        with kernels.tuning(**knobs):
+        with kernels.tuning(**{"SLM_W4_KS_MT2": 1, **knobs}):   # (opt-in kernel: not the default plan)
             out, ref = _run_gemm(case, bits, M, bias=(i % 2 == 1), seed=i)
         err = _rel_err(out, ref)
         assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, knobs, err)
@@ -420,6 +420,17 @@ def test_repeated_launches_are_bit_identical(M, K, N, env, tune):
 @pytest.mark.parametrize("M,K,N", [(256, 4096, 4096), (256, 14336, 4096), (32, 4096, 4096),
                                    (32, 14336, 4096), (7, 4096, 1024), (64, 4096, 4096), (48, 14336, 4096)])
 def test_deferred_splitk_reduce_into_rms_norm(M, K, N, dtype):
+    _deferred_check(M, K, N, dtype)
+
+
+@pytest.mark.parametrize("M,K,N", [(64, 4096, 4096), (48, 14336, 4096), (33, 2048, 6144)])
+def test_deferred_splitk_reduce_from_the_two_row_tile_stream(M, K, N, tune):
+    """the same hand-over with the slabs written by the opt-in two-row-tile K-sliced kernel (w4_ks.hip, MT = 2)"""
+    tune(SLM_W4_KS_MT2=2)
+    _deferred_check(M, K, N, "bf16")
+
+
+def _deferred_check(M, K, N, dtype):
     """SLM_W4_DEFER_REDUCE: a split-K GEMM leaves its fp32 slabs in the workspace and
     slm_rms_norm_splitk sums them itself -- same order and rounding as the reduce kernel, so
     out / residual must equal "GEMM -> reduce -> slm_rms_norm(+residual)" bit for bit."""
@@ -440,7 +451,7 @@ def test_deferred_splitk_reduce_into_rms_norm(M, K, N, dtype):
     out, res = torch.empty_like(c), res0.clone()
     kernels.rms_norm(out, c2, w, 1e-5, res, partials=h)
     torch.cuda.synchronize()
-    if (M, K, N) in ((256, 14336, 4096), (32, 14336, 4096), (64, 4096, 4096), (48, 14336, 4096)):
+    if (M, K, N) in ((256, 14336, 4096), (32, 14336, 4096), (64, 4096, 4096), (48, 14336, 4096)):  # (all split over K)
         assert int(h) >= 2, "the down-projection shapes are split over K"
     if not h:
         assert torch.equal(c2, c)

@@ -56,10 +56,10 @@ PLANS = [
     (32, 4096, 1024, 128, dict(SLM_W4_SPLITK=4)),
     (24, 1024, 512, 128, dict(SLM_W4_SMALL=0, SLM_W4_SPLITK=1)),  # general kernel MT = 1 (POST form)
     (24, 1024, 512, 128, dict(SLM_W4_SMALL=0, SLM_W4_SPLITK=1, SLM_W4_NTW=2)),  # pair inside one wave
-    (48, 1024, 512, 128, dict(SLM_W4_SPLITK=1, SLM_W4_KS_MT2=0)),  # general kernel, MT = 2
-    (48, 1024, 512, 128, dict()),                                # K-sliced stream, two row tiles: in-kernel pair
-    (64, 4096, 1024, 128, dict()),                               # ... split over 4 workgroups: fused reduce
-    (33, 2048, 448, 128, dict(SLM_W4_KS_TPW=4)),                 # ... ragged tile runs, one row in tile 2
+    (48, 1024, 512, 128, dict(SLM_W4_SPLITK=1)),                 # general kernel, MT = 2
+    (48, 1024, 512, 128, dict(SLM_W4_KS_MT2=1)),                 # K-sliced stream, two row tiles: in-kernel pair
+    (64, 4096, 1024, 128, dict(SLM_W4_KS_MT2=1)),                # ... split over 4 workgroups: fused reduce
+    (33, 2048, 448, 128, dict(SLM_W4_KS_MT2=1, SLM_W4_KS_TPW=4)),  # ... ragged tile runs, one row in tile 2
     (64, 1024, 512, 32, dict(SLM_W4_SPLITK=2)),
     (100, 1024, 512, 128, dict(SLM_W4_MT=4, SLM_W4_SPLITK=1)),   # MT = 4 (PRE form)
     (128, 2048, 1024, 128, dict(SLM_W4_MT=4, SLM_W4_SPLITK=2)),
