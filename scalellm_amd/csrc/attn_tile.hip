@@ -46,6 +46,8 @@ struct TileMfma<f16_tag> {
   }
 };
 
+// (s_setprio 1 around the two MFMA clusters was measured on this form: chunked 8 x 256 over 4 k +1 %,
+// causal 1 x 2048 -13 % -- the long query tile's co-resident partner starves it; not used)
 // KV rows per tile: 32 (one S^T block per wave and tile) or 64 (two: KVT template parameter)
 // V tile in LDS: HD/16 sub-tiles of [32 kv][16 d] bf16 (32 B per kv row, 1 KiB per sub-tile), the
 // image ds_read_b64_tr_b16 gathers from: a 16-lane group reads a [4 kv][16 d] block (lane t points
