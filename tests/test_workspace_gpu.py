@@ -50,7 +50,7 @@ def test_graph_replay_survives_workspace_growth():
 
     step_a()  # warm-up sizes the workspace (as ModelRunner does before capture)
     torch.cuda.synchronize()
-    ws_a = kernels._workspaces[("cuda", 0)]
+    ws_a = kernels._workspaces[kernels._dev_key(DEV)]
     ptr_a, size_a = ws_a.data_ptr(), ws_a.numel()
     ref_out, ref_c = out_a.clone(), c_a.clone()
     ga = torch.cuda.CUDAGraph()
@@ -66,7 +66,7 @@ def test_graph_replay_survives_workspace_growth():
     need_more = kernels.reserve_workspace(size_a + 1).numel()
     _attn(q2, kc2, vc2, params2, B, 128, out_b, 4096)
     torch.cuda.synchronize()
-    ws_b = kernels._workspaces[("cuda", 0)]
+    ws_b = kernels._workspaces[kernels._dev_key(DEV)]
     assert ws_b.data_ptr() != ptr_a and need_more >= 2 * size_a, "the workspace did not grow"
     assert kernels.retired_workspace_bytes() >= size_a, "the old buffer was released"
     # the allocator must NOT be able to hand graph A's scratch to anybody: allocate a lot of
@@ -135,7 +135,7 @@ def test_deferred_partials_are_isolated_and_versioned():
     q, kc, vc, params, B, D = _decode_case(2, 2048, seed=9)
     _attn(q, kc, vc, params, B, D, torch.empty_like(q), 2048)
     kernels.gptq_gemm(a, packed, torch.empty_like(c))
-    ws = kernels._workspaces[("cuda", 0)]
+    ws = kernels._workspaces[kernels._dev_key(DEV)]
     ws.view(torch.float32)[: ws.numel() // 4].fill_(float("nan"))
     out = torch.empty_like(c)
     kernels.rms_norm(out, c2, w, 1e-5, partials=h)
