@@ -664,7 +664,13 @@ def main():
     # HBM traffic of that launch from the PMC counters, measured IN THIS RUN (rank 0, N = 1): two
     # rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) over a child process
     # that launches the same kernel on the same shapes; null when rocprofv3 is unavailable
-    gemm = measure_gemm(model, bs)  # (before the profiler children below: same clocks as the timed steps)
+    # the gate_up GEMM at the row count the step launches it with (a lane's rows under two lanes), and at
+    # the full batch for continuity with rounds 1-3 (before the profiler children below: same clocks
+    # as the timed steps)
+    gemm = measure_gemm(model, attn_rows)
+    if attn_rows != bs:
+        gemm["rows_note"] = f"M = {attn_rows}: the rows of one of the step's two lanes"
+        gemm["at_full_batch"] = measure_gemm(model, bs)
     traffic, traffic_src = (None, None)
     if rank == 0 and world == 1 and not args.no_traffic:
         traffic, traffic_src = measure_attention_traffic_live(attn_rows, L, model.n_heads, model.n_kv_heads, B)
