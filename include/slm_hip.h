@@ -110,7 +110,13 @@ typedef struct slm_attn_args {
   void* workspace;          /* split-KV scratch, may be NULL if bytes == 0    */
   size_t workspace_bytes;
   int32_t num_splits;       /* 0 = auto (heuristic); >0 forces the split count */
-  int32_t reserved;
+  int32_t total_kv_len;     /* scheduling hint, 0 = unknown: kv_cu_lens[batch] if the host has it
+                             * (Batch::prepare_model_input builds cu_seq_lens on the host, batch.cpp:137).
+                             * total_kv_len == batch_size * max_kv_len tells the plan that every sequence
+                             * has max_kv_len tokens: a pure-decode call that needs no KV split then skips
+                             * the balanced partition and with it the combine launch that would find
+                             * nothing to merge.  Like max_kv_len it only shapes the launch: results are
+                             * correct whatever the value (a wrong "uniform" claim costs balance, not bits) */
 } slm_attn_args;
 
 /* Scratch needed for `a` (depends only on host-side sizes; AttentionHandler::

@@ -33,6 +33,7 @@ def cpp_params(params):
     q.q_cu_seq_lens, q.kv_cu_seq_lens = params.q_cu_seq_lens, params.kv_cu_seq_lens
     q.new_cache_slots, q.block_tables, q.cu_block_lens = params.new_cache_slots, params.block_tables, params.cu_block_lens
     q.q_max_seq_len, q.kv_max_seq_len = int(params.q_max_seq_len), int(params.kv_max_seq_len)
+    q.kv_total_len = int(getattr(params, "kv_total_len", 0))
     return q
 
 

@@ -756,7 +756,15 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
   // (bs = 24 ragged 63.9 us classic vs 71.6 balanced; bs = 32, 4 splits: 80.3 vs 75.7)
   const bool bal_pays = ((1 << pl->hpw_shift) << pl->hgw_shift) >= 4 &&
                         a->max_kv_len / (pl->n_splits > 0 ? pl->n_splits : 1) >= 768;
-  if (bal_mode != 0 && ((a->n_tokens >= 16 && bal_pays) || bal_mode == 2) && a->max_q_len <= 1 &&
+  // the host says every sequence has max_kv_len tokens (slm_attn_args::total_kv_len) and the classic
+  // plan needs no KV split: one workgroup per (token, head group) already IS the balanced partition
+  // -- and writes the final rows itself, so the call is ONE launch (the balanced form would add a
+  // combine launch that finds nothing to merge: ~5 us per layer, 64 times per two-lane step).  A wrong
+  // claim is still computed correctly: the classic partition follows the device-side lengths.
+  const bool uniform_hint = a->total_kv_len > 0 && bal_mode != 2 &&
+                            (int64_t)a->total_kv_len == (int64_t)a->batch_size * a->max_kv_len;
+  if (bal_mode != 0 && !(uniform_hint && n_splits == 1) &&
+      ((a->n_tokens >= 16 && bal_pays) || bal_mode == 2) && a->max_q_len <= 1 &&
       a->n_tokens == a->batch_size &&
       a->sliding_window < 0 && forced_splits <= 0 && !decode_on_tile(a) && a->n_tokens > 0) {
     int slots = n_splits + 1 > 9 ? n_splits + 1 : 9;

@@ -60,6 +60,9 @@ struct InputParameters {
   torch::Tensor new_cache_slots;  // [n_tokens] int32
   torch::Tensor block_tables;     // [n_blocks] int32, first-slot ids (batch.cpp:206-209)
   torch::Tensor cu_block_lens;    // [n_seq + 1] int32
+  // extension (not in models/parameters.h): cu_seq_lens.back() as Batch::prepare_model_input has it on the
+  // host (batch.cpp:137), 0 = unknown -- a scheduling hint like the two maxima (slm_attn_args::total_kv_len)
+  int64_t kv_total_len = 0;
 };
 
 // handler.h:15-48

@@ -200,6 +200,8 @@ std::vector<LlamaForCausalLMHip::Lane> LlamaForCausalLMHip::make_lanes(int64_t T
       ln.params.kv_cu_seq_lens = kv_cu;
       ln.params.new_cache_slots = p.new_cache_slots.narrow(0, r0, n);
       ln.params.cu_block_lens = p.cu_block_lens.narrow(0, r0, n + 1);
+      // the halves of a uniform batch are uniform (the one case the hint distinguishes); else unknown
+      ln.params.kv_total_len = p.kv_total_len == T * static_cast<int64_t>(p.kv_max_seq_len) ? n * p.kv_max_seq_len : 0;
     }
     ln.resid = resid_.narrow(0, r0, n); ln.normed = normed_.narrow(0, r0, n);
     ln.qkv = qkv_.narrow(0, r0, n); ln.attn = attn_.narrow(0, r0, n);
@@ -300,6 +302,7 @@ void LlamaForCausalLMHip::attn(Lane& ln, size_t li, std::vector<KVCache>& kv) {
   a.max_q_len = p.q_max_seq_len; a.max_kv_len = p.kv_max_seq_len;
   a.sm_scale = handler_->sm_scale(); a.logits_soft_cap = handler_->logits_soft_cap();
   a.sliding_window = -1;
+  a.total_kv_len = p.kv_total_len > 0 && p.kv_total_len < (int64_t(1) << 31) ? static_cast<int32_t>(p.kv_total_len) : 0;
   if (a.n_tokens == 0 || a.batch_size == 0) return;
   const size_t need = slm_paged_kv_varlen_mha_workspace_bytes(&a);
   if (need > 0) {

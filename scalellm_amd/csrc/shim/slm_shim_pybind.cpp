@@ -126,7 +126,8 @@ PYBIND11_MODULE(_slm_shim, m) {
       .def_readwrite("q_max_seq_len", &slm::InputParameters::q_max_seq_len)
       .def_readwrite("new_cache_slots", &slm::InputParameters::new_cache_slots)
       .def_readwrite("block_tables", &slm::InputParameters::block_tables)
-      .def_readwrite("cu_block_lens", &slm::InputParameters::cu_block_lens);
+      .def_readwrite("cu_block_lens", &slm::InputParameters::cu_block_lens)
+      .def_readwrite("kv_total_len", &slm::InputParameters::kv_total_len);
   py::class_<slm::HipAttnHandler>(m, "HipAttnHandler")
       .def(py::init([](float sm_scale, float logits_soft_cap, int64_t rotary_dim, int64_t max_position,
                        torch::Tensor inv_freq, bool interleaved, int device_index) {

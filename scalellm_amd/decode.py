@@ -318,7 +318,11 @@ class LlamaDecodeStep:
                     q_cu_seq_lens=st["q_cu"], kv_cu_seq_lens=st["kv_cu"],
                     new_cache_slots=params.new_cache_slots[r0:r1], block_tables=params.block_tables,
                     cu_block_lens=params.cu_block_lens[r0:r1 + 1], q_max_seq_len=params.q_max_seq_len,
-                    kv_max_seq_len=params.kv_max_seq_len)
+                    kv_max_seq_len=params.kv_max_seq_len,
+                    # every sequence at the maximum <=> the whole batch is: the halves of a uniform batch
+                    # are uniform (the only case the hint distinguishes); otherwise unknown
+                    kv_total_len=(r1 - r0) * params.kv_max_seq_len
+                    if getattr(params, "kv_total_len", 0) == T * params.kv_max_seq_len else 0)
             ln.resid, ln.normed = b["resid"][r0:r1], b["normed"][r0:r1]
             ln.alt = b["resid_alt"][:T] if fold else None
             ln.qkv, ln.attn, ln.act = b["qkv"][r0:r1], b["attn"][r0:r1], b["act"][r0:r1]
@@ -596,7 +600,7 @@ def make_batch_inputs(q_lens, kv_lens, block_size: int, device, seed: int = 0, v
     tokens = torch.randint(0, vocab, (sum(q_lens),), device=device, generator=g).to(torch.int32)
     params = InputParameters(q_cu_seq_lens=q_cu, kv_cu_seq_lens=kv_cu, new_cache_slots=slots,
                              block_tables=table, cu_block_lens=cu_blk, q_max_seq_len=max(q_lens),
-                             kv_max_seq_len=max(kv_lens))
+                             kv_max_seq_len=max(kv_lens), kv_total_len=sum(kv_lens))
     return tokens, positions, params, n_blocks
 
 
@@ -621,5 +625,5 @@ def make_decode_inputs(batch: int, kv_len: int, block_size: int, device, seed: i
     tokens = torch.randint(0, vocab, (batch * q_len,), device=device, generator=g).to(torch.int32)
     params = InputParameters(q_cu_seq_lens=q_cu, kv_cu_seq_lens=kv_cu, new_cache_slots=slots,
                              block_tables=table, cu_block_lens=cu_blk, q_max_seq_len=q_len,
-                             kv_max_seq_len=kv_len)
+                             kv_max_seq_len=kv_len, kv_total_len=batch * kv_len)
     return tokens, positions, params, n_blocks

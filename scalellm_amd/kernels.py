@@ -244,6 +244,8 @@ def paged_kv_varlen_mha(
     logits_soft_cap: float = 0.0,
     sliding_window: int = -1,
     num_splits: int = 0,          # extension: 0 = heuristic, >0 forces the split-KV count
+    total_kv_len: int = 0,        # extension: kv_cu_lens[batch] if the HOST knows it (a scheduling hint like
+                                  # max_kv_len, slm_attn_args::total_kv_len), 0 = unknown
 ) -> None:
     """Mirror of llm::paged_kv_varlen_mha (attn_api.h:12-27): writes `out` in place, async
     on the current stream."""
@@ -251,6 +253,7 @@ def paged_kv_varlen_mha(
     a = _attn_args(out, query, key_cache, value_cache, q_cu_lens, kv_cu_lens, block_table,
                    block_cu_lens, alibi_slopes, block_size, max_q_len, max_kv_len, sm_scale,
                    logits_soft_cap, sliding_window, num_splits)
+    a.total_kv_len = int(total_kv_len) if 0 < int(total_kv_len) < 2 ** 31 else 0
     if a.n_tokens == 0 or a.batch_size == 0:
         return
     need = L.slm_paged_kv_varlen_mha_workspace_bytes(C.byref(a))

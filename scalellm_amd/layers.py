@@ -35,6 +35,10 @@ class InputParameters:
     cu_block_lens: torch.Tensor       # [batch + 1] int32
     q_max_seq_len: int = 0
     kv_max_seq_len: int = 0
+    # extension (not in models/parameters.h): cu_seq_lens.back() as Batch::prepare_model_input has it on
+    # the host (batch.cpp:137); 0 = unknown.  A scheduling hint like the two maxima above: lets the
+    # attention plan recognise a uniform batch (kernels.paged_kv_varlen_mha, total_kv_len)
+    kv_total_len: int = 0
 
 
 class KVCache:
@@ -109,7 +113,8 @@ class HipAttnHandler:
                                     input_params.cu_block_lens, self.alibi_slopes,
                                     kv_cache.block_size(), input_params.q_max_seq_len,
                                     input_params.kv_max_seq_len, self.sm_scale,
-                                    self.logits_soft_cap, sliding_window)
+                                    self.logits_soft_cap, sliding_window,
+                                    total_kv_len=getattr(input_params, "kv_total_len", 0))
 
 
 class Attention:
