@@ -51,6 +51,12 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* tbl = reinterpret_cast<int*>(smem);
   float* xch = reinterpret_cast<float*>(smem + ATTN_TBL_ENT * sizeof(int));
+  // Wave priority (SLM_ATTN_PRIO, p.prio): in the two-lane decode step (decode.py) this kernel shares
+  // the CUs with the other lane's int4 GEMMs.  The KV stream is the step's critical resource and the
+  // GEMMs are filler: with a raised priority the stream's waves win the issue arbitration against
+  // co-resident GEMM waves, which then run in the gaps the stream leaves (its waves wait on HBM most
+  // of the time).  No effect when the kernel has the chip to itself.
+  if (p.prio > 0) __builtin_amdgcn_s_setprio(3);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -902,6 +908,7 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
   kp.rows_lo = 0;
   kp.rows_hi = 0x7fffffff;
   kp.bal = pl.bal; kp.part_slots = pl.part_slots; kp.bal_qmin = pl.bal_qmin; kp.bal_align = ATTN_BAL_ALIGN;
+  kp.prio = tune_get(TUNE_ATTN_PRIO, 1);  // measured on the two-lane bs 256 step: 25.08 -> 24.85 ms (2 x 2 runs)
   if (pl.n_splits > 1 || pl.bal) {
     const size_t need =
         (size_t)a->n_tokens * a->n_heads * pl.part_slots * (a->head_dim + 2) * sizeof(float);

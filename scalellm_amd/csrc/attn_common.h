@@ -45,6 +45,7 @@ struct AttnKParams {
   int bal_qmin;    // bounds the pieces of one sequence by part_slots
   int bal_align;
   int part_slots;  // partial slots per (token, head): n_splits (classic) or the piece bound (balanced)
+  int prio;        // > 0: the token kernel raises its wave priority (attn.hip)
 };
 
 // the piece size of the balanced partition: ONE formula for the stream kernel and the combine kernel
