@@ -462,7 +462,7 @@ torch::Tensor LlamaForCausalLMHip::decode_step(const torch::Tensor& tokens, cons
   const auto last = (input_params.q_cu_seq_lens.index({Slice(1, torch::indexing::None)}) - 1).to(torch::kLong);
   const auto lg = logits(h, last);
   if (return_logits) return lg;
-  return torch::argmax(lg.to(torch::kFloat), -1).to(torch::kInt);
+  return torch::argmax(lg, -1).to(torch::kInt);  // (16-bit logits: same index as the fp32 argmax, no 4-byte copy)
 }
 
 }  // namespace slm

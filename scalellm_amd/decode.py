@@ -511,7 +511,9 @@ class LlamaDecodeStep:
             logits = gather_from_model_parallel_region(logits, pa)
         if return_logits:
             return logits
-        return torch.argmax(logits.float(), dim=-1).to(torch.int32)
+        # (on the 16-bit logits: the widening is exact and monotonic, so the index is the one the fp32
+        # argmax would give -- without writing and re-reading a 4-byte copy of [n_seqs, vocab])
+        return torch.argmax(logits, dim=-1).to(torch.int32)
 
 
     def _greedy_over_vocab_shards(self, logits: torch.Tensor, ar) -> torch.Tensor:
