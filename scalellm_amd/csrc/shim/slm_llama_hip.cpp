@@ -163,6 +163,13 @@ int64_t LlamaForCausalLMHip::lane_split(int64_t T, const InputParameters& p) con
   if (p.q_max_seq_len != 1 || T != n_seqs || T < 64) return 0;
   if (opt_.decode_lanes < 0) {
     if (!((96 <= T && T <= 160) || (232 <= T && T <= 256))) return 0;
+    // ... and only while the KV stream dominates the layer (>= 8 x the layer's weight bytes)
+    const int64_t kv_bytes = 4 * n_kv_heads_ * args_.head_dim * T * static_cast<int64_t>(p.kv_max_seq_len);
+    const int64_t tp = parallel_args_.world_size();
+    const int64_t w_bytes = (args_.hidden_size * (n_heads_ + 2 * n_kv_heads_) * args_.head_dim +
+                             n_heads_ * args_.head_dim * args_.hidden_size +
+                             3 * args_.hidden_size * args_.intermediate_size / tp) / 2;
+    if (kv_bytes < 8 * w_bytes) return 0;
   } else if (T < opt_.decode_lanes) {
     return 0;
   }

@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256, (POST && PC * MT == 4 && MT < 4) ? 1 : 2)
   uint32_t szcur[NTW][PC][NG], sznext[NTW][PC][NG];
   auto w_issue = [&](int t, int h, int cfirst) {  // half-chunk h of the pass starting at cfirst
     const uint32_t* wp = p.wq + ((((int64_t)cfirst * 2 + h) * n_tiles + ntile[t]) * 64 + lane) * 4;
-    wreg[t][h] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp));
+    wreg[t][h] = *reinterpret_cast<const u32x4*>(wp);  // EXPERIMENT: plain (cacheable) weight loads
   };
   auto sz_load = [&](uint32_t (&dst)[NTW][PC][NG], int cfirst) {
 #pragma unroll

@@ -293,6 +293,18 @@ class LlamaDecodeStep:
             # M = 129 tile step, 2 x 157 us instead of one 175-250 us launch set; no change at 64.
             if not (96 <= T <= 160 or 232 <= T <= 256):
                 return 0
+            # ... and only while the KV stream dominates the layer: the lanes hide GEMM time under
+            # attention time, and with little attention to hide under they only pay their costs (each
+            # lane's GEMMs at half the rows, the co-run contention).  Measured (same file): 8B bs 256 at
+            # kv_len 4096 / 2048 / 1024 / 512 = 36 / 18 / 9 / 4.5 x the layer's weight bytes: +7 / +3 / +2 /
+            # -5 %; bs 128 at 1024 (4.5 x) -1 %; Llama-3-70B shapes bs 128 at 4096 (5 x) -7 %.
+            s = self.shape
+            kv_bytes = 4 * self.n_kv_heads * s.head_dim * T * params.kv_max_seq_len
+            tp = self.pa.world_size
+            w_bytes = (s.hidden * (self.n_heads + 2 * self.n_kv_heads) * s.head_dim +
+                       self.n_heads * s.head_dim * s.hidden + 3 * s.hidden * s.intermediate // tp) // 2
+            if kv_bytes < 8 * w_bytes:
+                return 0
         elif T < self.lanes_min:
             return 0
         return (T // 2 + 31) // 32 * 32
