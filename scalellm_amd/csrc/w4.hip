@@ -245,7 +245,13 @@ __global__ void __launch_bounds__(256, (POST && PC * MT == 4 && MT < 4) ? 1 : 2)
   uint32_t szcur[NTW][PC][NG], sznext[NTW][PC][NG];
   auto w_issue = [&](int t, int h, int cfirst) {  // half-chunk h of the pass starting at cfirst
     const uint32_t* wp = p.wq + ((((int64_t)cfirst * 2 + h) * n_tiles + ntile[t]) * 64 + lane) * 4;
-    wreg[t][h] = *reinterpret_cast<const u32x4*>(wp);  // EXPERIMENT: plain (cacheable) weight loads
+    // plain (cacheable) loads, not non-temporal ones (round 4): a layer's weights are re-read within
+    // ~0.4 ms -- by the second BM = 64 row block at M = 65...128 and by the second lane of the two-lane
+    // decode step -- and a cacheable line is still in the Infinity Cache then.  Two-lane bs 256 step
+    // 24.85 -> 23.98 ms, one lane 26.1 -> 25.9; stand-alone with rotating weights 3-6 % slower (124 ->
+    // 132 us per layer at M = 128): the step is what counts.  The kernels that read every weight once
+    // per launch (w4_ks / w4_gemv: M <= 32; w4_ws at M = 256) keep their nt loads.
+    wreg[t][h] = *reinterpret_cast<const u32x4*>(wp);
   };
   auto sz_load = [&](uint32_t (&dst)[NTW][PC][NG], int cfirst) {
 #pragma unroll

@@ -60,7 +60,10 @@ static_assert(WS_AL <= WS_A_UNITS - 1, "the slot of unit g + WS_AL must have bee
 #define WS_STR(x) WS_STR2(x)
 
 // NGC: scale groups per 64-deep chunk (2 for group 32, else 1)
-template <typename T, int NGC>
+// WNT: non-temporal weight loads -- right when every weight is read ONCE per launch (one block of 256
+// rows: the decode batch), wrong when several row blocks re-read the weights (prefill: cacheable lines
+// are served from L2 / Infinity Cache the second time; round 4: M = 1024 layer 533 -> 508 us)
+template <typename T, int NGC, bool WNT>
 __global__ void __launch_bounds__(512, 2) w4a16_gemm_ws_kernel(const GemmKParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Mfma<T>::frag frag_t;
@@ -188,7 +191,8 @@ __global__ void __launch_bounds__(512, 2) w4a16_gemm_ws_kernel(const GemmKParams
   uint32_t szreg[WS_WD][NGC];
   auto w_load = [&](int c, u32x4& w, uint32_t (&sz)[NGC]) {
     const uint32_t* wp = p.wq + (((int64_t)c * n_tiles + nt) * 64 + lane) * 4;
-    w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp));
+    if constexpr (WNT) w = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp));
+    else w = *reinterpret_cast<const u32x4*>(wp);
 #pragma unroll
     for (int g = 0; g < NGC; ++g) {
       const int64_t grp = ((int64_t)c * 64 + g * (64 / NGC)) >> p.gs_shift;
@@ -344,9 +348,9 @@ __global__ void __launch_bounds__(512, 2) w4a16_gemm_ws_kernel(const GemmKParams
   }
 }
 
-template <typename T, int NGC>
+template <typename T, int NGC, bool WNT>
 static void launch_ws(const GemmKParams& kp, int n_blocks, hipStream_t st) {
-  auto kfn = w4a16_gemm_ws_kernel<T, NGC>;
+  auto kfn = w4a16_gemm_ws_kernel<T, NGC, WNT>;
   static bool opted = false;  // > 64 KiB of dynamic LDS has to be opted into once per kernel
   if (!opted) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
@@ -358,12 +362,13 @@ static void launch_ws(const GemmKParams& kp, int n_blocks, hipStream_t st) {
 
 void launch_gemm_ws(const GemmKParams& kp, int dtype, int ng, int n_blocks, hipStream_t st) {
   // ng = scale groups per 128 of K (w4.hip plan): 4 for group 32 -> 2 per 64-deep chunk
+  const bool once = kp.n_mblocks <= 1;  // every weight read by one row block only: stream it past the caches
   if (dtype == SLM_BF16) {
-    if (ng == 4) launch_ws<bf16_tag, 2>(kp, n_blocks, st);
-    else launch_ws<bf16_tag, 1>(kp, n_blocks, st);
+    if (ng == 4) (once ? launch_ws<bf16_tag, 2, true>(kp, n_blocks, st) : launch_ws<bf16_tag, 2, false>(kp, n_blocks, st));
+    else (once ? launch_ws<bf16_tag, 1, true>(kp, n_blocks, st) : launch_ws<bf16_tag, 1, false>(kp, n_blocks, st));
   } else {
-    if (ng == 4) launch_ws<f16_tag, 2>(kp, n_blocks, st);
-    else launch_ws<f16_tag, 1>(kp, n_blocks, st);
+    if (ng == 4) (once ? launch_ws<f16_tag, 2, true>(kp, n_blocks, st) : launch_ws<f16_tag, 2, false>(kp, n_blocks, st));
+    else (once ? launch_ws<f16_tag, 1, true>(kp, n_blocks, st) : launch_ws<f16_tag, 1, false>(kp, n_blocks, st));
   }
 }
 
