@@ -15,7 +15,7 @@ const char* const kTuneNames[TUNE_COUNT] = {
     "SLM_ATTN_TILE_SPLITS", "SLM_ATTN_TILE_PF",     "SLM_ATTN_U",       "SLM_ATTN_NT",
     "SLM_ATTN_TILE_DECODE", "SLM_ATTN_BAL",         "SLM_ATTN_PRIO",
     "SLM_W4_GEMV",          "SLM_W4_GEMV_KS",   "SLM_W4_SMALL",
-    "SLM_W4_MT",            "SLM_W4_NTW",           "SLM_W4_PC",        "SLM_W4_SPLITK",
+    "SLM_W4_MT",            "SLM_W4_MT_WIDE",       "SLM_W4_NTW",           "SLM_W4_PC",        "SLM_W4_SPLITK",
     "SLM_W4_POST",
     "SLM_W4_KS",            "SLM_W4_KS_CW",         "SLM_W4_KS_NW",     "SLM_W4_KS_TPW",
     "SLM_W4_KS_DBG",        "SLM_W4_KS_MT2",

@@ -26,6 +26,7 @@ enum TuneKey : int {
   TUNE_W4_GEMV_KS,        // SLM_W4_GEMV_KS        forced K slices per GEMV workgroup (1/2/4/8)
   TUNE_W4_SMALL,          // SLM_W4_SMALL          0 = never use the small-M kernel
   TUNE_W4_MT,             // SLM_W4_MT             forced M tile (1/2/4/8/16)
+  TUNE_W4_MT_WIDE,        // SLM_W4_MT_WIDE        forced M tile of wide layers (N >= 16384) at 64 < M <= 128
   TUNE_W4_NTW,            // SLM_W4_NTW
   TUNE_W4_PC,             // SLM_W4_PC
   TUNE_W4_SPLITK,         // SLM_W4_SPLITK         forced split-K

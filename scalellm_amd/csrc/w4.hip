@@ -574,6 +574,7 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
                a->K * a->N / 2 < ((int64_t)1 << 32) && (a->K / gs) * a->N * 4 < ((int64_t)1 << 32) &&
                ((a->M - 1) * a->lda + a->K) * 2 < ((int64_t)1 << 31)) ? 1 : 0;
   mt = tune_get(TUNE_W4_MT, mt);
+  if (a->M > 64 && a->M <= 128 && a->N >= 16384) mt = tune_get(TUNE_W4_MT_WIDE, mt);  // (wide layers: gate_up)
   if (pl->small) mt = 1;
   // 8 = wave-specialised 256 x 128 kernel (w4_ws.hip), 16 = symmetric 256 x 256 kernel (w4_xl.hip)
   if (mt != 1 && mt != 2 && mt != 4 && mt != 8 && mt != 16) mt = 4;

@@ -110,6 +110,43 @@ def _shard_rows(ck, fmt, k0, k1, group_size, bits=4):
             "scales": ck["scales"][k0 // group_size:k1 // group_size].contiguous()}
 
 
+def two_lane_split(shape: "LlamaShape", n_heads: int, n_kv_heads: int, world_size: int, lanes_min: int,
+                   n_tokens: int, n_seqs: int, q_max_seq_len: int, kv_max_seq_len: int) -> int:
+    """Rows of lane 0 when a step runs as two half-batch lanes (LlamaDecodeStep._run_two_lanes; the
+    same rule in csrc/shim/slm_llama_hip.cpp), else 0.  Pure host logic on the step's hints.
+
+    Two lanes need: one rank, a pure decode batch in the reference's graph-replay sense (every sequence
+    brings exactly one token: q_max_seq_len == 1 and n_tokens == n_seqs, the condition ModelRunner
+    replays on, model_runner.cpp:112-140, under which q_cu_seq_lens is the identity), and -- lanes_min:
+    -1 = auto, 0 = never, N = every such batch of >= N tokens (tests, sweeps; SLM_DECODE_LANES).
+
+    auto: where two lanes were measured faster on one MI355X (Llama-3-8B shapes, 4 k context,
+    profiles/r04_lanes_sweep.jsonl): T = 96 +3.2 %, 128 +6.4 %, 160 +1.4 %, 256 +3.4..5.4 %; slower at
+    192 (-3.7 %: 96-sequence attention launches fill the CUs badly), 224 (-7 %), 320 (-6 %), 384 (-2 %):
+    halves beyond 128 rows put BOTH lanes' GEMMs past the M = 129 tile step, 2 x 157 us instead of one
+    175-250 us launch set; no change at 64.  And only while the KV stream dominates the layer: the
+    lanes hide GEMM time under attention time, and with little attention to hide under they only pay
+    their costs.  Measured: 8B bs 256 at kv_len 4096 / 2048 / 1024 / 512 = 36 / 18 / 9 / 4.5 x the layer's
+    weight bytes: +7 / +3 / +2 / -5 %; bs 128 at 1024 (4.5 x) -1 %; Llama-3-70B shapes bs 128 at 4096
+    (5 x) -7 %."""
+    T = n_tokens
+    if lanes_min == 0 or world_size != 1:
+        return 0
+    if q_max_seq_len != 1 or T != n_seqs or T < 64:
+        return 0
+    if lanes_min < 0:
+        if not (96 <= T <= 160 or 232 <= T <= 256):
+            return 0
+        kv_bytes = 4 * n_kv_heads * shape.head_dim * T * kv_max_seq_len
+        w_bytes = (shape.hidden * (n_heads + 2 * n_kv_heads) * shape.head_dim +
+                   n_heads * shape.head_dim * shape.hidden + 3 * shape.hidden * shape.intermediate // world_size) // 2
+        if kv_bytes < 8 * w_bytes:
+            return 0
+    elif T < lanes_min:
+        return 0
+    return (T // 2 + 31) // 32 * 32
+
+
 class LlamaDecodeStep:
     def __init__(self, shape: LlamaShape, max_batch_tokens: int, n_blocks: int, block_size: int,
                  parallel_args: Optional[ParallelArgs] = None, quant_method: str = "awq",
@@ -275,39 +312,11 @@ class LlamaDecodeStep:
                      "attn", "act", "gate_up", "o_buf", "down_buf", "pend", "fold", "stream", "q", "ar")
 
     def _lane_split(self, T: int, params: InputParameters, ar) -> int:
-        """Rows of lane 0 when the step runs as two lanes, else 0.  Two lanes need: one rank, a pure
-        decode batch in the reference's graph-replay sense (every sequence brings exactly one token:
-        q_max_seq_len == 1 and n_tokens == n_seqs, the condition ModelRunner replays on,
-        model_runner.cpp:112-140, under which q_cu_seq_lens is the identity), and enough rows that
-        the half-batch GEMMs stay efficient (SLM_DECODE_LANES: auto / 0 = never / N = from N tokens on)."""
-        n_seqs = params.q_cu_seq_lens.numel() - 1
-        if self.lanes_min == 0 or ar is not None or self.pa.world_size != 1:
+        """Rows of lane 0 when the step runs as two lanes, else 0 (two_lane_split below)."""
+        if ar is not None:
             return 0
-        if params.q_max_seq_len != 1 or T != n_seqs or T < 64:
-            return 0
-        if self.lanes_min < 0:
-            # auto: where two lanes were measured faster on one MI355X (Llama-3-8B shapes, 4 k context,
-            # profiles/r04_lanes_sweep.jsonl): T = 96 +3.2 %, 128 +6.4 %, 160 +1.4 %, 256 +3.4..5.4 %;
-            # slower at 192 (-3.7 %: 96-sequence attention launches fill the CUs badly), 224 (-7 %),
-            # 320 (-6 %), 384 (-2 %): halves beyond 128 rows put BOTH lanes' GEMMs past the
-            # M = 129 tile step, 2 x 157 us instead of one 175-250 us launch set; no change at 64.
-            if not (96 <= T <= 160 or 232 <= T <= 256):
-                return 0
-            # ... and only while the KV stream dominates the layer: the lanes hide GEMM time under
-            # attention time, and with little attention to hide under they only pay their costs (each
-            # lane's GEMMs at half the rows, the co-run contention).  Measured (same file): 8B bs 256 at
-            # kv_len 4096 / 2048 / 1024 / 512 = 36 / 18 / 9 / 4.5 x the layer's weight bytes: +7 / +3 / +2 /
-            # -5 %; bs 128 at 1024 (4.5 x) -1 %; Llama-3-70B shapes bs 128 at 4096 (5 x) -7 %.
-            s = self.shape
-            kv_bytes = 4 * self.n_kv_heads * s.head_dim * T * params.kv_max_seq_len
-            tp = self.pa.world_size
-            w_bytes = (s.hidden * (self.n_heads + 2 * self.n_kv_heads) * s.head_dim +
-                       self.n_heads * s.head_dim * s.hidden + 3 * s.hidden * s.intermediate // tp) // 2
-            if kv_bytes < 8 * w_bytes:
-                return 0
-        elif T < self.lanes_min:
-            return 0
-        return (T // 2 + 31) // 32 * 32
+        return two_lane_split(self.shape, self.n_heads, self.n_kv_heads, self.pa.world_size, self.lanes_min, T,
+                              params.q_cu_seq_lens.numel() - 1, params.q_max_seq_len, params.kv_max_seq_len)
 
     def _make_lanes(self, T: int, positions, params: InputParameters, o_buf, down_buf, ar, fold):
         b = self.buf

@@ -181,3 +181,30 @@ def test_plan_uneven_groups_of_an_act_order_shard():
             assert len(gset) <= 1 and (not gset or gset == {int(block_group[b])})
         # padding overhead is bounded by 31 rows per group present + the 128-row tail
         assert kp <= ks + 31 * int((torch.bincount(g_idx, minlength=n_groups) > 0).sum()) + 127
+
+
+def test_two_lane_policy_table():
+    """decode.two_lane_split: pure host logic on the step's hints (the C++ host step holds the same rule,
+    slm_llama_hip.cpp; tests/test_cpp_host_step_gpu.py checks the two agree on real batches)."""
+    from scalellm_amd.decode import LlamaShape, two_lane_split
+    s8, s70 = LlamaShape.llama3_8b(), LlamaShape.llama3_70b()
+
+    def auto(T, kv=4096, shape=s8, heads=(32, 8), world=1, n_seqs=None, q_max=1):
+        return two_lane_split(shape, heads[0], heads[1], world, -1, T, T if n_seqs is None else n_seqs, q_max, kv)
+
+    # measured window at 4 k context (profiles/r04_lanes_sweep.jsonl); lane 0 gets a multiple of 32 rows
+    assert [auto(T) for T in (32, 64, 96, 128, 160, 192, 224, 232, 256, 257, 320, 384)] == \
+        [0, 0, 64, 64, 96, 0, 0, 128, 128, 0, 0, 0]
+    # the KV stream has to dominate the layer's weight bytes (>= 8 x)
+    assert auto(256, kv=2048) == 128 and auto(256, kv=1024) == 128 and auto(256, kv=512) == 0
+    assert auto(128, kv=1024) == 0
+    assert auto(128, shape=s70, heads=(64, 8)) == 0
+    # never across ranks, never for batches that are not one token per sequence
+    assert auto(256, world=8, heads=(4, 1)) == 0
+    assert auto(256, n_seqs=100) == 0 and auto(256, n_seqs=64, q_max=4) == 0
+    # explicit settings: 0 = never, N = every pure decode batch of >= max(N, 64) tokens, whatever the context
+    assert two_lane_split(s8, 32, 8, 1, 0, 256, 256, 1, 4096) == 0
+    assert two_lane_split(s8, 32, 8, 1, 64, 192, 192, 1, 16) == 96
+    assert two_lane_split(s8, 32, 8, 1, 64, 100, 100, 1, 16) == 64
+    assert two_lane_split(s8, 32, 8, 1, 200, 192, 192, 1, 4096) == 0
+    assert two_lane_split(s8, 32, 8, 1, 1, 48, 48, 1, 4096) == 0
