@@ -150,8 +150,13 @@ void LlamaForCausalLMHip::reserve(int64_t n_tokens) {
   for (int l = 0; l < lanes; ++l) {
     scratch(l, need);
     for (int s = 0; s < 2; ++s) deferred(l, s, static_cast<size_t>(16) * n_tokens * widest * 4);
-    lane_q_cu_[l] = torch::zeros({n_tokens + 1}, torch::dtype(torch::kInt).device(options_.device()));
-    lane_kv_cu_[l] = torch::zeros({n_tokens + 1}, torch::dtype(torch::kInt).device(options_.device()));
+    // (grown, never shrunk or replaced in place: a captured graph replays against these addresses too)
+    if (!lane_q_cu_[l].defined() || lane_q_cu_[l].size(0) < n_tokens + 1) {
+      TORCH_CHECK(!capturing(), "LlamaForCausalLMHip: call reserve() before graph capture");
+      if (lane_q_cu_[l].defined()) { retired_.push_back(lane_q_cu_[l]); retired_.push_back(lane_kv_cu_[l]); }
+      lane_q_cu_[l] = torch::zeros({n_tokens + 1}, torch::dtype(torch::kInt).device(options_.device()));
+      lane_kv_cu_[l] = torch::zeros({n_tokens + 1}, torch::dtype(torch::kInt).device(options_.device()));
+    }
   }
 }
 
