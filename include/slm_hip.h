@@ -341,6 +341,21 @@ SLM_API int slm_rms_norm(void* out, const void* x, const void* weight, void* res
 SLM_API int slm_rms_norm_splitk(void* out, const float* partials /* [n_splits, n_tokens, dim] */,
                                 int32_t n_splits, const void* weight, void* residual,
                                 int64_t n_tokens, int64_t dim, float eps, int32_t dtype, void* stream);
+/* LayerNorm with weight and optional bias (bias == NULL: none), fp32 statistics, one rounding:
+ * out = T((x - mean) * rsqrt(var + eps) * weight + bias).  replaces kernel::layer_norm
+ * (src/kernels/layernorm_kernels.cu:185-256; LayerNormImpl::forward src/layers/normalization.h:86-95)
+ * for the LayerNorm model families (GPT-2: BASELINE configs[0], GPT-NeoX, Bloom, MPT).  dim % 8 == 0,
+ * dim <= 16384, contiguous rows. */
+SLM_API int slm_layer_norm(void* out, const void* x, const void* weight, const void* bias /* or NULL */,
+                           int64_t n_tokens, int64_t dim, float eps, int32_t dtype, void* stream);
+/* tanh-form GELU: kind = SLM_GELU_NEW (kernel::gelu_new, GPT-2's "gelu_new") or SLM_GELU_FAST
+ * (kernel::gelu_fast), src/kernels/activation_kernels.cu:20-40,111-120.  with_mul = 0: out [T, d] =
+ * act(x [T, d]);  with_mul = 1: out [T, d] = T(act(x[:, :d])) * x[:, d:], x [T, 2 d]
+ * (gelu_new_with_mul / gelu_fast_with_mul, activation_kernels.cu:128-145).  d % 8 == 0. */
+#define SLM_GELU_NEW 0
+#define SLM_GELU_FAST 1
+SLM_API int slm_gelu(void* out, const void* x, int64_t n_tokens, int64_t d, int32_t kind, int32_t with_mul,
+                     int32_t dtype, void* stream);
 /* Rotary embedding applied in place to q and k, fused with the KV append that always follows it
  * (src/layers/attention/attention.cpp:36-42).  cos_sin row = [cos(rot/2) | sin(rot/2)] per
  * position (the reference cache layout, pos_embedding_kernels.cu:41: [max_pos, 2, rot/2]), either

@@ -237,6 +237,26 @@ def silu_mul(x) -> np.ndarray:
     return out
 
 
+def layer_norm(x, weight, bias, eps: float) -> np.ndarray:
+    """F::layer_norm over the last dimension (src/layers/normalization.h:54-61); bias None = no bias."""
+    x, w = _f32(x), _f32(weight)
+    b = _f32(bias) if bias is not None else None
+    out = np.empty_like(x)
+    lib().oracle_layer_norm(_p(x, _f32p), _p(w, _f32p), _p(b, _f32p) if b is not None else None, _p(out, _f32p),
+                            C.c_int64(x.shape[0]), C.c_int64(x.shape[1]), C.c_float(eps))
+    return out
+
+
+def gelu(x, kind: str = "new", with_mul: bool = False) -> np.ndarray:
+    """gelu_new / gelu_fast and their *_with_mul forms (src/layers/activation.cpp:24-34, 57-65)."""
+    x = _f32(x)
+    d = x.shape[1] // 2 if with_mul else x.shape[1]
+    out = np.empty((x.shape[0], d), dtype=np.float32)
+    lib().oracle_gelu(_p(x, _f32p), _p(out, _f32p), C.c_int64(x.shape[0]), C.c_int64(d),
+                      C.c_int32({"new": 0, "fast": 1}[kind]), C.c_int32(1 if with_mul else 0))
+    return out
+
+
 def allreduce_sum(partials) -> np.ndarray:
     """SUM all-reduce: what every rank holds after ProcessGroup::allreduce
     (src/model_parallel/process_group.cpp:135-153); the reference's own test pins it to the

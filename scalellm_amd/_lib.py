@@ -157,6 +157,10 @@ def lib() -> C.CDLL:
           C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
         ("slm_silu_mul", C.c_int,
          [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+        ("slm_layer_norm", C.c_int,
+         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_float, C.c_int32, C.c_void_p]),
+        ("slm_gelu", C.c_int,
+         [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
         ("slm_decode_advance", C.c_int,
          [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
           C.c_void_p, C.c_void_p]),

@@ -10,6 +10,11 @@
 //                         src/layers/attention/attention.cpp:36-42, so K is rotated in registers and
 //                         written once to its in-place location and once to its cache slot.
 //  slm_silu_mul        <- kernel::act_and_mul (silu), src/kernels/activation_kernels.cu:84.
+//  slm_layer_norm      <- kernel::layer_norm (src/kernels/layernorm_kernels.cu:185-256; CPU path
+//                         F::layer_norm, src/layers/normalization.h:54-61): GPT-2 / GPT-NeoX / Bloom / MPT.
+//  slm_gelu            <- kernel::gelu_new / gelu_fast and their *_with_mul forms
+//                         (src/kernels/activation_kernels.cu:20-40, 111-145; CPU path
+//                         src/layers/activation.cpp:24-34, 57-65).
 #include "common.h"
 
 namespace slm {
@@ -298,6 +303,122 @@ __global__ void __launch_bounds__(256) silu_mul_kernel(uint16_t* __restrict__ ou
   }
 }
 
+// LayerNorm, one workgroup per token: the row stays in registers between the three passes (mean,
+// centred variance, normalise) -- the reference kernel re-reads it from memory for each
+// (layernorm_kernels.cu:198-226).  out = T((x - mean) * rsqrt(var + eps) * w + b), all in fp32, ONE
+// rounding at the end (unlike RMSNorm, which rounds before the weight: layernorm_kernels.cu:222-227).
+template <typename T, int NV>
+__global__ void __launch_bounds__(256) layer_norm_kernel(uint16_t* __restrict__ out,
+                                                         const uint16_t* __restrict__ x,
+                                                         const uint16_t* __restrict__ weight,
+                                                         const uint16_t* __restrict__ bias, int64_t dim,
+                                                         float eps) {
+  __shared__ float red[2][4];
+  const int64_t tok = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int64_t nvec = dim / 8;
+  u32x4 a[NV], wv[NV], bv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {  // every load unconditional (index clamped, contribution masked)
+    const int64_t vic = min((int64_t)tid + 256 * i, nvec - 1);
+    wv[i] = *reinterpret_cast<const u32x4*>(weight + vic * 8);
+    bv[i] = bias ? *reinterpret_cast<const u32x4*>(bias + vic * 8) : u32x4{0u, 0u, 0u, 0u};
+    a[i] = *reinterpret_cast<const u32x4*>(x + tok * dim + vic * 8);
+  }
+  float v[NV][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const bool valid = (int64_t)tid + 256 * i < nvec;
+    const float f[8] = {lo_f32<T>(a[i].x), hi_f32<T>(a[i].x), lo_f32<T>(a[i].y), hi_f32<T>(a[i].y),
+                        lo_f32<T>(a[i].z), hi_f32<T>(a[i].z), lo_f32<T>(a[i].w), hi_f32<T>(a[i].w)};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[i][j] = f[j];
+      if (valid) sum += f[j];
+    }
+  }
+  sum = wave_sum64(sum);
+  if ((tid & 63) == 0) red[0][tid >> 6] = sum;
+  __syncthreads();
+  const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)dim;
+  float var = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const bool valid = (int64_t)tid + 256 * i < nvec;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[i][j] -= mean;
+      if (valid) var = __builtin_fmaf(v[i][j], v[i][j], var);
+    }
+  }
+  var = wave_sum64(var);
+  if ((tid & 63) == 0) red[1][tid >> 6] = var;
+  __syncthreads();
+  const float rs = rsqrtf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)dim + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int64_t vi = tid + 256 * i;
+    if (vi < nvec) {
+      const float w[8] = {lo_f32<T>(wv[i].x), hi_f32<T>(wv[i].x), lo_f32<T>(wv[i].y), hi_f32<T>(wv[i].y),
+                          lo_f32<T>(wv[i].z), hi_f32<T>(wv[i].z), lo_f32<T>(wv[i].w), hi_f32<T>(wv[i].w)};
+      const float b[8] = {lo_f32<T>(bv[i].x), hi_f32<T>(bv[i].x), lo_f32<T>(bv[i].y), hi_f32<T>(bv[i].y),
+                          lo_f32<T>(bv[i].z), hi_f32<T>(bv[i].z), lo_f32<T>(bv[i].w), hi_f32<T>(bv[i].w)};
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = v[i][j] * rs * w[j] + b[j];
+      u32x4 r;
+      r.x = pack2<T>(o[0], o[1]); r.y = pack2<T>(o[2], o[3]);
+      r.z = pack2<T>(o[4], o[5]); r.w = pack2<T>(o[6], o[7]);
+      *reinterpret_cast<u32x4*>(out + tok * dim + vi * 8) = r;
+    }
+  }
+}
+
+// tanh-form GELU (activation_kernels.cu:20-40): x * 0.5 (1 + tanh(u)), u = 0.79788456 (x + 0.044715 x^3)
+// ("new", GPT-2) or 0.79788456 x (1 + 0.044715 x^2) ("fast") -- the same polynomial, two roundings apart.
+// 0.5 (1 + tanh(u)) = 1 / (1 + 2^(-2 u log2 e)): one exp2 + one rcp, saturating correctly at both ends
+// (the reference uses tanh.approx.f32, abs error ~5e-4; this form is good to ~1e-7).
+template <bool FAST>
+__device__ __forceinline__ float gelu_tanh1(const float x) {
+  const float u = FAST ? (0.7978845608028654f * x) * (1.0f + 0.044715f * x * x)
+                       : 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  return x * __builtin_amdgcn_rcpf(1.0f + fast_exp2(u * (-2.0f * 1.4426950408889634f)));
+}
+
+// out[t, i] = gelu(x[t, i])                    (MUL = false; x row stride d)
+// out[t, i] = gelu(x[t, i]) * x[t, d + i]      (MUL = true;  x row stride 2 d: activation.cpp:57-65)
+template <typename T, bool FAST, bool MUL>
+__global__ void __launch_bounds__(256) gelu_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ x,
+                                                   int64_t n_tokens, int64_t d) {
+  const int64_t nvec = d / 8;
+  const int64_t total = n_tokens * nvec;
+  const int64_t xs = MUL ? 2 * d : d;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t t = idx / nvec, vi = idx % nvec;
+    const u32x4 g = *reinterpret_cast<const u32x4*>(x + t * xs + vi * 8);
+    u32x4 u = {0u, 0u, 0u, 0u};
+    if constexpr (MUL) u = *reinterpret_cast<const u32x4*>(x + t * xs + d + vi * 8);
+    const float gf[8] = {lo_f32<T>(g.x), hi_f32<T>(g.x), lo_f32<T>(g.y), hi_f32<T>(g.y),
+                         lo_f32<T>(g.z), hi_f32<T>(g.z), lo_f32<T>(g.w), hi_f32<T>(g.w)};
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = gelu_tanh1<FAST>(gf[j]);
+    if constexpr (MUL) {
+      // the reference rounds the activation to T before the multiply (activation_kernels.cu:62-80: the
+      // functor returns T): same here
+      const float uf[8] = {lo_f32<T>(u.x), hi_f32<T>(u.x), lo_f32<T>(u.y), hi_f32<T>(u.y),
+                           lo_f32<T>(u.z), hi_f32<T>(u.z), lo_f32<T>(u.w), hi_f32<T>(u.w)};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = lo_f32<T>((uint32_t)pack1<T>(o[j])) * uf[j];
+    }
+    u32x4 r;
+    r.x = pack2<T>(o[0], o[1]); r.y = pack2<T>(o[2], o[3]);
+    r.z = pack2<T>(o[4], o[5]); r.w = pack2<T>(o[6], o[7]);
+    *reinterpret_cast<u32x4*>(out + t * d + vi * 8) = r;
+  }
+}
+
 }  // namespace slm
 
 using namespace slm;
@@ -468,6 +589,60 @@ SLM_API int slm_silu_mul(void* out, const void* x, int64_t n_tokens, int64_t d, 
                        (const uint16_t*)x, n_tokens, d);
   else
     return SLM_ERR_UNSUPPORTED;
+  return hip_check_launch();
+}
+
+SLM_API int slm_layer_norm(void* out, const void* x, const void* weight, const void* bias, int64_t n_tokens,
+                           int64_t dim, float eps, int32_t dtype, void* stream) {
+  if (n_tokens == 0) return SLM_OK;
+  if (!out || !x || !weight || n_tokens < 0) return SLM_ERR_INVALID_ARG;
+  if (dim <= 0 || dim % 8 || dim > 16384) return SLM_ERR_UNSUPPORTED;
+  if (!aligned16(out) || !aligned16(x) || !aligned16(weight) || (bias && !aligned16(bias))) return SLM_ERR_ALIGNMENT;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hip_clear_error();
+  const dim3 grid((unsigned)n_tokens), blk(256);
+  const int64_t per_thread = (dim / 8 + 255) / 256;
+#define SLM_LN(TT, NVV)                                                                             \
+  hipLaunchKernelGGL((layer_norm_kernel<TT, NVV>), grid, blk, 0, st, (uint16_t*)out, (const uint16_t*)x, \
+                     (const uint16_t*)weight, (const uint16_t*)bias, dim, eps)
+#define SLM_LN_NV(TT)                                                                               \
+  do {                                                                                              \
+    if (per_thread <= 1) SLM_LN(TT, 1); else if (per_thread <= 2) SLM_LN(TT, 2);                    \
+    else if (per_thread <= 4) SLM_LN(TT, 4); else SLM_LN(TT, 8);                                    \
+  } while (0)
+  if (dtype == SLM_BF16) SLM_LN_NV(bf16_tag);
+  else if (dtype == SLM_F16) SLM_LN_NV(f16_tag);
+  else return SLM_ERR_UNSUPPORTED;
+#undef SLM_LN_NV
+#undef SLM_LN
+  return hip_check_launch();
+}
+
+SLM_API int slm_gelu(void* out, const void* x, int64_t n_tokens, int64_t d, int32_t kind, int32_t with_mul,
+                     int32_t dtype, void* stream) {
+  if (n_tokens == 0) return SLM_OK;
+  if (!out || !x || n_tokens < 0) return SLM_ERR_INVALID_ARG;
+  if (kind != SLM_GELU_NEW && kind != SLM_GELU_FAST) return SLM_ERR_INVALID_ARG;
+  if (d <= 0 || d % 8) return SLM_ERR_UNSUPPORTED;
+  if (!aligned16(out) || !aligned16(x)) return SLM_ERR_ALIGNMENT;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hip_clear_error();
+  const int64_t total = n_tokens * (d / 8);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  const dim3 grid((unsigned)blocks), blk(256);
+#define SLM_GELU(TT, FF, MM)                                                                        \
+  hipLaunchKernelGGL((gelu_kernel<TT, FF, MM>), grid, blk, 0, st, (uint16_t*)out, (const uint16_t*)x, n_tokens, d)
+#define SLM_GELU_T(TT)                                                                              \
+  do {                                                                                              \
+    if (kind == SLM_GELU_FAST) { if (with_mul) SLM_GELU(TT, true, true); else SLM_GELU(TT, true, false); } \
+    else { if (with_mul) SLM_GELU(TT, false, true); else SLM_GELU(TT, false, false); }              \
+  } while (0)
+  if (dtype == SLM_BF16) SLM_GELU_T(bf16_tag);
+  else if (dtype == SLM_F16) SLM_GELU_T(f16_tag);
+  else return SLM_ERR_UNSUPPORTED;
+#undef SLM_GELU_T
+#undef SLM_GELU
   return hip_check_launch();
 }
 

@@ -43,6 +43,14 @@ PYBIND11_MODULE(_slm_shim, m) {
   m.def("silu_and_mul",
         [](torch::Tensor out, torch::Tensor input) { llm::kernel::silu_and_mul(out, input); });
   m.def("silu_with_mul", &llm::kernel::silu_with_mul, py::arg("input"));
+  m.def("layer_norm", [](torch::Tensor out, torch::Tensor input, torch::Tensor weight,
+                         std::optional<torch::Tensor> bias, float eps) {
+    llm::kernel::layer_norm(out, input, weight, bias.has_value() ? *bias : torch::Tensor(), eps);
+  });
+  m.def("gelu_new", &llm::kernel::gelu_new, py::arg("input"));
+  m.def("gelu_fast", &llm::kernel::gelu_fast, py::arg("input"));
+  m.def("gelu_new_with_mul", &llm::kernel::gelu_new_with_mul, py::arg("input"));
+  m.def("gelu_fast_with_mul", &llm::kernel::gelu_fast_with_mul, py::arg("input"));
   // scalellm/csrc/kernels.cu:24-54, verbatim names and keyword arguments: `_C.kernels`
   m.def("marlin_sz_cache_entries", &slm::marlin_sz_cache_entries);
   m.def("marlin_gemm",

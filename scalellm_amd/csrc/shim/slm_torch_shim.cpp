@@ -211,6 +211,36 @@ void silu_and_mul(torch::Tensor& out, torch::Tensor input) {
         "slm_silu_mul");
 }
 
+void layer_norm(torch::Tensor& out, torch::Tensor input, torch::Tensor weight, torch::Tensor bias, float epsilon) {
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input.device());
+  TORCH_CHECK(input.is_contiguous() && out.is_contiguous(), "layer_norm: contiguous tensors");  // (the reference DCHECKs)
+  const int64_t dim = input.size(-1);
+  check(slm_layer_norm(out.mutable_data_ptr(), input.const_data_ptr(), weight.const_data_ptr(),
+                       bias.defined() ? bias.const_data_ptr() : nullptr, input.numel() / dim, dim, epsilon,
+                       dtype_code(input), current_stream(input)),
+        "slm_layer_norm");
+}
+
+namespace {
+torch::Tensor gelu_impl(const torch::Tensor& input, int kind, bool with_mul) {
+  c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(input.device());
+  TORCH_CHECK(input.is_contiguous() && (!with_mul || input.size(-1) % 2 == 0));
+  auto sizes = input.sizes().vec();
+  if (with_mul) sizes.back() /= 2;
+  auto out = torch::empty(sizes, input.options());
+  const int64_t d = sizes.back();
+  check(slm_gelu(out.mutable_data_ptr(), input.const_data_ptr(), out.numel() / d, d, kind, with_mul ? 1 : 0,
+                 dtype_code(input), current_stream(input)),
+        "slm_gelu");
+  return out;
+}
+}  // namespace
+
+torch::Tensor gelu_new(torch::Tensor input) { return gelu_impl(input, SLM_GELU_NEW, false); }
+torch::Tensor gelu_fast(torch::Tensor input) { return gelu_impl(input, SLM_GELU_FAST, false); }
+torch::Tensor gelu_new_with_mul(torch::Tensor input) { return gelu_impl(input, SLM_GELU_NEW, true); }
+torch::Tensor gelu_fast_with_mul(torch::Tensor input) { return gelu_impl(input, SLM_GELU_FAST, true); }
+
 torch::Tensor silu_with_mul(torch::Tensor input) {
   // activation_kernels.cu:84-ff: out [..., d] = silu(input[..., :d]) * input[..., d:]
   TORCH_CHECK(input.is_contiguous() && input.size(-1) % 2 == 0);

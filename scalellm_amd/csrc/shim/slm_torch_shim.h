@@ -65,6 +65,14 @@ void rms_norm_residual(torch::Tensor& out, torch::Tensor& residual, torch::Tenso
 torch::Tensor silu_with_mul(torch::Tensor input);
 // the same into a caller-owned buffer (graph-captured steps reuse static buffers)
 void silu_and_mul(torch::Tensor& out, torch::Tensor input);
+// src/kernels/layernorm_kernels.h:22-26 (the LayerNorm model families: GPT-2, GPT-NeoX, Bloom, MPT);
+// bias undefined = no bias (layernorm_kernels.cu:250)
+void layer_norm(torch::Tensor& out, torch::Tensor input, torch::Tensor weight, torch::Tensor bias, float epsilon);
+// src/kernels/activation_kernels.h:6-7, 12-13
+torch::Tensor gelu_new(torch::Tensor input);
+torch::Tensor gelu_fast(torch::Tensor input);
+torch::Tensor gelu_new_with_mul(torch::Tensor input);
+torch::Tensor gelu_fast_with_mul(torch::Tensor input);
 
 }  // namespace kernel
 }  // namespace llm

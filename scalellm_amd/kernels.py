@@ -754,6 +754,63 @@ def rms_norm(out: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, eps: floa
           "slm_rms_norm")
 
 
+def layer_norm(out: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+               eps: float) -> None:
+    """kernel::layer_norm (layernorm_kernels.cu:231-256): out = T((x - mean) * rsqrt(var + eps) * weight
+    + bias) per row, fp32 statistics; bias None = no bias (bias.defined() false in the reference)."""
+    L = _lib.lib()
+    _require_gpu(out, x, weight, bias)
+    if not (x.is_contiguous() and out.is_contiguous() and weight.is_contiguous()) or \
+            (bias is not None and not bias.is_contiguous()):
+        raise SlmError("layer_norm needs contiguous tensors")
+    dim = x.size(-1)
+    if weight.numel() != dim or (bias is not None and bias.numel() != dim) or out.shape != x.shape:
+        raise SlmError("layer_norm: weight / bias / out do not match the input's last dimension")
+    check(L.slm_layer_norm(out.data_ptr(), x.data_ptr(), weight.data_ptr(),
+                           bias.data_ptr() if bias is not None else None, x.numel() // dim, dim, float(eps),
+                           _dtype_code(x), _stream()), "slm_layer_norm")
+
+
+GELU_NEW, GELU_FAST = 0, 1
+
+
+def _gelu(x: torch.Tensor, kind: int, with_mul: bool, out: Optional[torch.Tensor]) -> torch.Tensor:
+    L = _lib.lib()
+    _require_gpu(x, out)
+    if x.dim() != 2 or not x.is_contiguous():
+        raise SlmError("gelu needs a contiguous [n_tokens, d] input")
+    d = x.size(1) // 2 if with_mul else x.size(1)
+    if with_mul and x.size(1) % 2:
+        raise SlmError("gelu_with_mul needs an even number of columns")
+    if out is None:
+        out = torch.empty(x.size(0), d, dtype=x.dtype, device=x.device)
+    elif tuple(out.shape) != (x.size(0), d) or not out.is_contiguous() or out.dtype != x.dtype:
+        raise SlmError("gelu: out must be a contiguous [n_tokens, d] tensor of the input's dtype")
+    check(L.slm_gelu(out.data_ptr(), x.data_ptr(), x.size(0), d, kind, 1 if with_mul else 0, _dtype_code(x),
+                     _stream()), "slm_gelu")
+    return out
+
+
+def gelu_new(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """kernel::gelu_new (activation_kernels.cu:111-114): 0.5 x (1 + tanh(0.79788456 (x + 0.044715 x^3)))."""
+    return _gelu(x, GELU_NEW, False, out)
+
+
+def gelu_fast(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """kernel::gelu_fast (activation_kernels.cu:116-119): 0.5 x (1 + tanh(0.79788456 x (1 + 0.044715 x^2)))."""
+    return _gelu(x, GELU_FAST, False, out)
+
+
+def gelu_new_with_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """kernel::gelu_new_with_mul (activation_kernels.cu:128-135): gelu_new(x[:, :d]) * x[:, d:]."""
+    return _gelu(x, GELU_NEW, True, out)
+
+
+def gelu_fast_with_mul(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """kernel::gelu_fast_with_mul (activation_kernels.cu:137-144)."""
+    return _gelu(x, GELU_FAST, True, out)
+
+
 def apply_rotary_pos_emb(query: torch.Tensor, key: torch.Tensor, positions: torch.Tensor,
                          cos_sin: torch.Tensor, rotary_dim: int, interleaved: bool,
                          value: Optional[torch.Tensor] = None,

@@ -12,6 +12,10 @@ the reference so parity tests read like the reference's own layer tests.
                           src/layers/quantization/qlinear_awq_marlin_impl.cpp:128-366,
                           qlinear_gptq_marlin_impl.cpp:74-330 (TP sharding dims, lazy repack on
                           first forward, all-reduce then bias for row-parallel)
+  LayerNorm            <- llm::LayerNormImpl          src/layers/normalization.h:68-110
+  Activation           <- llm::Activation             src/layers/activation.h:36-46, activation.cpp:80-140
+                          (the LayerNorm model families -- GPT-2, BASELINE configs[0] -- next to the
+                          RMSNorm / SiLU pair the Llama path uses)
 """
 from __future__ import annotations
 
@@ -317,3 +321,78 @@ class RowParallelQLinear(_QLinearBase):
             return y
         return self._gemm(x, self.bias if self.has_bias else None, out,
                           defer_splitk=defer_splitk and not self.has_bias)
+
+
+class LayerNorm:
+    """llm::LayerNormImpl (normalization.h:68-110): LayerNormImpl(dim, eps, bias, options);
+    forward = kernel::layer_norm on the GPU (normalization.h:86-91) -> slm_layer_norm."""
+
+    def __init__(self, dim: int, eps: float, bias: bool, dtype: torch.dtype = torch.float16, device="cuda"):
+        self.eps = float(eps)
+        self.weight = torch.empty(dim, dtype=dtype, device=device)
+        self.bias = torch.zeros(dim, dtype=dtype, device=device) if bias else None
+        self._loaded = {"weight": False, "bias": not bias}
+
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor]) -> None:
+        """normalization.h:98-118: copy `weight` (and `bias`) when present; shapes must match."""
+        for name in ("weight", "bias"):
+            t = state_dict.get(name)
+            dst = getattr(self, name)
+            if t is None or dst is None:
+                continue
+            if tuple(t.shape) != tuple(dst.shape):
+                raise ValueError(f"{name} size mismatch: {tuple(t.shape)} vs {tuple(dst.shape)}")
+            dst.copy_(t)
+            self._loaded[name] = True
+
+    def verify_loaded_weights(self, prefix: str = "") -> None:
+        for name, ok in self._loaded.items():
+            if not ok:
+                raise RuntimeError(f"weight is not loaded for {prefix}{name}")
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:  # noqa: A002 (the reference's argument name)
+        out = torch.empty_like(input)
+        x2 = input.view(-1, input.size(-1))
+        kernels.layer_norm(out.view(-1, input.size(-1)), x2, self.weight, self.bias, self.eps)
+        return out
+
+    __call__ = forward
+
+
+class Activation:
+    """llm::Activation (activation.h:36-46).  The names with a custom kernel in the reference
+    (gelu_new, gelu_fast, silu: activation.cpp:87-104, 117-134) run on their HIP replacements; the
+    names the reference itself leaves to torch on every device (gelu, gelu_pytorch_tanh, relu) stay
+    torch expressions here too -- and so does plain `silu` WITHOUT the multiply (kernel::silu,
+    activation_kernels.cu:121-125), which no gated-MLP model calls: the hot path uses silu_with_mul."""
+
+    @staticmethod
+    def get_act_func(name: str):
+        import torch.nn.functional as F
+        n = name.lower()
+        table = {"gelu_new": kernels.gelu_new, "gelu_fast": kernels.gelu_fast,
+                 "gelu": F.gelu, "gelu_pytorch_tanh": lambda x: F.gelu(x, approximate="tanh"),
+                 "relu": F.relu, "silu": F.silu}
+        if n not in table:
+            raise ValueError(f"Unsupported activation function: {name}")  # (activation.cpp:106)
+        return table[n]
+
+    @staticmethod
+    def get_act_with_mul_func(name: str):
+        import torch.nn.functional as F
+        n = name.lower()
+
+        def chunked(f):
+            return lambda x: f(x.chunk(2, dim=-1)[0]) * x.chunk(2, dim=-1)[1]
+
+        def silu_with_mul(x):
+            out = torch.empty(x.size(0), x.size(1) // 2, dtype=x.dtype, device=x.device)
+            kernels.silu_and_mul(out, x)
+            return out
+
+        table = {"gelu_new": kernels.gelu_new_with_mul, "gelu_fast": kernels.gelu_fast_with_mul,
+                 "silu": silu_with_mul, "gelu": chunked(F.gelu),
+                 "gelu_pytorch_tanh": chunked(lambda x: F.gelu(x, approximate="tanh")), "relu": chunked(F.relu)}
+        if n not in table:
+            raise ValueError(f"Unsupported activation function: {name}")
+        return table[n]

@@ -25,7 +25,7 @@ def _declared_symbols():
 def test_header_declares_the_expected_entry_points():
     syms = _declared_symbols()
     for must in ("slm_paged_kv_varlen_mha", "slm_set_kv_cache", "slm_w4_prepack", "slm_w4a16_gemm",
-                 "slm_rms_norm", "slm_rope_kv_append", "slm_silu_mul", "slm_decode_advance",
+                 "slm_rms_norm", "slm_rope_kv_append", "slm_silu_mul", "slm_layer_norm", "slm_gelu", "slm_decode_advance",
                  "slm_allreduce", "slm_allreduce_simulate", "slm_shm_alloc", "slm_shm_export",
                  "slm_shm_import", "slm_ar_signal_bytes"):
         assert must in syms

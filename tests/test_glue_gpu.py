@@ -1,6 +1,8 @@
 """GPU parity for the glue ops: RMSNorm(+residual), RoPE fused with the KV
 append, SiLU*mul -- against the oracle's restatements of src/layers/normalization.h:17-52,
-src/layers/pos_embedding.cpp (detail::apply_rotary_pos_emb) and activation_kernels.cu:84."""
+src/layers/pos_embedding.cpp (detail::apply_rotary_pos_emb) and activation_kernels.cu:84; and the
+LayerNorm / tanh-GELU pair of the LayerNorm model families (GPT-2: BASELINE configs[0]) against
+F::layer_norm and activation.cpp:24-34, 57-65."""
 import numpy as np
 import pytest
 import torch
@@ -147,3 +149,92 @@ def test_rope_append_splitk_rejects_foreign_layouts():
     kernels.apply_rotary_pos_emb(q, k, pos, cs, D, False, partials=h)
     with pytest.raises(kernels.SlmError, match="handle"):
         kernels.apply_rotary_pos_emb(q, k, pos, cs, D, False, partials=object())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("tokens,dim", [(1, 768), (37, 1600), (256, 8192), (5, 16384), (3, 8)])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_layer_norm(dtype, tokens, dim, with_bias):
+    """kernel::layer_norm (layernorm_kernels.cu:185-256): fp32 statistics, one rounding of
+    (x - mean) rsqrt(var + eps) w + b.  Through the C ABI (kernels.layer_norm) and the shim's
+    llm::kernel::layer_norm -- same bits; rows with a large mean (var << mean^2) included."""
+    from scalellm_amd import cpp_host, kernels
+    g = torch.Generator(device=DEV).manual_seed(dim + tokens)
+    x = torch.randn(tokens, dim, device=DEV, dtype=dtype, generator=g) * 1.7
+    x[0] += 6.0                                   # centred variance, not E[x^2] - E[x]^2
+    w = (1 + 0.1 * torch.randn(dim, device=DEV, generator=g)).to(dtype)
+    b = (0.1 * torch.randn(dim, device=DEV, generator=g)).to(dtype) if with_bias else None
+    out = torch.full_like(x, float("nan"))
+    kernels.layer_norm(out, x, w, b, 1e-5)
+    torch.cuda.synchronize()
+    ref = oracle.layer_norm(x.float().cpu().numpy(), w.float().cpu().numpy(),
+                            b.float().cpu().numpy() if with_bias else None, 1e-5)
+    got = out.float().cpu().numpy()
+    # one rounding to T of an fp32 result: half an ulp of T, relative to |ref| (+ the fp32 statistics' slack)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    np.testing.assert_allclose(got, ref, rtol=ulp * 1.01, atol=1e-5)
+    shim = cpp_host.load_shim()
+    out2 = torch.full_like(x, float("nan"))
+    shim.layer_norm(out2, x, w, b, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["new", "fast"])
+@pytest.mark.parametrize("with_mul", [False, True])
+def test_gelu(dtype, kind, with_mul):
+    """kernel::gelu_new / gelu_fast / *_with_mul (activation_kernels.cu:20-40, 111-145) against
+    activation.cpp:24-34, 57-65: fp32 evaluation, one rounding (with_mul: the activation is rounded to T
+    before the product, as the reference's functor returns T)."""
+    from scalellm_amd import cpp_host, kernels
+    T, d = 41, 3072
+    g = torch.Generator(device=DEV).manual_seed(d)
+    x = torch.randn(T, (2 if with_mul else 1) * d, device=DEV, dtype=dtype, generator=g) * 3
+    x[0, :8] = torch.tensor([0.0, -0.0, 30.0, -30.0, 1e-4, -7.5, 12.0, -12.0], device=DEV).to(dtype)
+    fn = {("new", False): kernels.gelu_new, ("fast", False): kernels.gelu_fast,
+          ("new", True): kernels.gelu_new_with_mul, ("fast", True): kernels.gelu_fast_with_mul}[(kind, with_mul)]
+    out = fn(x)
+    torch.cuda.synchronize()
+    xf = x.float().cpu().numpy()
+    tol = (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11) * 1.01   # half an ulp of T, relative
+    got = out.float().cpu().numpy()
+    # (1) the oracle (fp32, tanhf: the reference's own spelling).  In the negative tail 1 + tanh(u) cancels --
+    # at x = -4 it is 3.6e-5 with tanhf's 6e-8 of absolute error, 1.7e-3 relative -- so the fp32 spelling
+    # itself carries ~1e-7 |x| of absolute noise there, which `up` (|up| < 15) multiplies: the atol
+    if with_mul:
+        act_o = torch.from_numpy(oracle.gelu(xf[:, :d], kind)).to(dtype).float().numpy()   # T(act(x))
+        ref_o = act_o * xf[:, d:]
+    else:
+        ref_o = oracle.gelu(xf, kind)
+    np.testing.assert_allclose(got, ref_o, rtol=(3.1 if with_mul else 2) * tol, atol=2e-6)
+    # (2) the same expression in float64 (no cancellation noise): the kernel's 1 / (1 + 2^(-2 u log2 e)) form is
+    # within half an ulp of T of it, except where its own ~1e-6 relative error crosses a rounding boundary
+    g64 = xf[:, :d].astype(np.float64) if with_mul else xf.astype(np.float64)
+    u64 = 0.7978845608028654 * g64 * (1.0 + 0.044715 * g64 * g64) if kind == "fast" else \
+        0.7978845608028654 * (g64 + 0.044715 * g64 ** 3)
+    act64 = 0.5 * g64 * (1.0 + np.tanh(u64))
+    if with_mul:
+        act64 = torch.from_numpy(act64).to(dtype).double().numpy()
+        ref64 = act64 * xf[:, d:].astype(np.float64)
+    else:
+        ref64 = act64
+    sub = 2.0 ** -24 if dtype == torch.float16 else 0.0                     # half the fp16 subnormal spacing
+    assert np.mean(np.abs(got - ref64) <= tol * np.abs(ref64) + sub + 1e-12) > 0.999
+    assert got[0, 0] == 0.0 and got[0, 1] == 0.0 and not np.isnan(got).any()
+    shim = cpp_host.load_shim()
+    out2 = getattr(shim, "gelu_" + kind + ("_with_mul" if with_mul else ""))(x)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+
+
+def test_layer_norm_and_gelu_reject_what_they_do_not_cover():
+    from scalellm_amd import kernels
+    x = torch.randn(4, 100, device=DEV, dtype=torch.bfloat16)       # 100 % 8 != 0
+    w = torch.ones(100, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(kernels.SlmError):
+        kernels.layer_norm(torch.empty_like(x), x, w, None, 1e-5)
+    with pytest.raises(kernels.SlmError):
+        kernels.gelu_new(x)
+    with pytest.raises(kernels.SlmError):
+        kernels.layer_norm(torch.empty(4, 96, device=DEV, dtype=torch.bfloat16), x[:, :96], w[:96], None, 1e-5)  # not contiguous

@@ -339,3 +339,33 @@ def test_decode_advance_matches_a_full_host_rebuild():
     pos2 = np.asarray([B * cap[0] - 1], np.int32)
     _, _, _, missing = oracle.decode_advance(pos2, np.asarray([0, B * cap[0]], np.int32), table, bcu[:2], B)
     assert missing == 1
+
+
+def test_layer_norm_and_gelu_follow_the_references_cpu_path():
+    """The reference's CPU path for the LayerNorm model families IS these torch expressions
+    (F::layer_norm, src/layers/normalization.h:54-61; gelu_fast / gelu_new and their *_with_mul forms,
+    src/layers/activation.cpp:24-34, 57-65): the oracle's C restatements against them, fp32."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(5)
+    for tokens, dim in ((1, 768), (7, 1600), (33, 64)):
+        x = (rng.standard_normal((tokens, dim)) * 2 + 0.3).astype(np.float32)
+        w = (1 + 0.1 * rng.standard_normal(dim)).astype(np.float32)
+        b = (0.1 * rng.standard_normal(dim)).astype(np.float32)
+        for bias in (b, None):
+            want = F.layer_norm(torch.from_numpy(x), (dim,), torch.from_numpy(w),
+                                torch.from_numpy(bias) if bias is not None else None, 1e-5).numpy()
+            np.testing.assert_allclose(oracle.layer_norm(x, w, bias, 1e-5), want, rtol=2e-5, atol=2e-6)
+    x = (rng.standard_normal((9, 96)) * 3).astype(np.float32)
+    x[0, :6] = [0.0, -0.0, 30.0, -30.0, 1e-8, -7.5]
+    t = torch.from_numpy(x)
+    new = 0.5 * t * (1.0 + torch.tanh(0.7978845608028654 * (t + 0.044715 * torch.pow(t, 3.0))))
+    fast = 0.5 * t * (1.0 + torch.tanh(0.7978845608028654 * t * (1.0 + 0.044715 * t * t)))
+    np.testing.assert_allclose(oracle.gelu(x, "new"), new.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(oracle.gelu(x, "fast"), fast.numpy(), rtol=1e-5, atol=1e-6)
+    # GPT-2's activation is torch's own tanh approximation too (HF "gelu_new")
+    np.testing.assert_allclose(oracle.gelu(x, "new"), F.gelu(t, approximate="tanh").numpy(), rtol=1e-5, atol=1e-6)
+    a, g = t.chunk(2, dim=-1)
+    for kind, f in (("new", new), ("fast", fast)):
+        want = f[:, :48] * g
+        np.testing.assert_allclose(oracle.gelu(x, kind, with_mul=True), want.numpy(), rtol=1e-5, atol=1e-6)
