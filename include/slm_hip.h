@@ -94,7 +94,11 @@ typedef struct slm_attn_args {
   const float* alibi_slopes;     /* [n_heads] or NULL                         */
   int32_t dtype;            /* slm_dtype of out/query/caches                  */
   int32_t batch_size;
-  int32_t n_tokens;         /* = query.size(0) = q_cu_lens[batch]             */
+  int32_t n_tokens;         /* = query.size(0) = q_cu_lens[batch].  Only a pure-decode batch (max_q_len <= 1)
+                             * may carry MORE rows than q_cu_lens[batch]: the graph padding of batch.cpp:219-244,
+                             * left untouched.  (With max_q_len > 1 the plan relies on the equality: when
+                             * n_tokens == batch_size * max_q_len every sequence has max_q_len tokens and only
+                             * that row class is launched.) */
   int32_t n_heads;
   int32_t n_kv_heads;
   int32_t head_dim;         /* multiple of 8, <= 256                          */

@@ -919,12 +919,19 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
   bool tile_used = false;
   const bool dec_tile = decode_on_tile(a);
   const int first_tile_rows = dec_tile ? kp.group : kp.group + 1;  // smallest row count on the tile kernel
+  // Every sequence brings exactly max_q_len tokens (the q lengths are bounded by max_q_len -- the grid contract
+  // -- and add up to batch_size * max_q_len): ONE row class is populated, the launches of the others would only
+  // start and exit (2.5 us each: the token kernel and the one-wave tile class in front of a pure prefill were
+  // 8 % of a 65 us causal 1 x 2048 call).  Anything else (mixed batches) launches every class as before.
+  const bool uniform_q = a->max_q_len > 0 && (int64_t)a->batch_size * a->max_q_len == (int64_t)a->n_tokens;
+  bool token_rows_possible = true;
   if ((a->max_q_len > 1 || dec_tile) && a->num_splits <= 0 && attn_tile_supported(kp.head_dim) &&
       tune_get(TUNE_ATTN_TILE, 1) != 0) {
     hip_clear_error();
     const int64_t max_rows = (int64_t)a->max_q_len * kp.group;
     AttnKParams tk = kp;
-    if (first_tile_rows < 33) {  // (group >= 32: every multi-row sequence already has > 32 rows)
+    token_rows_possible = !(uniform_q && max_rows >= first_tile_rows);
+    if (first_tile_rows < 33 && !(uniform_q && max_rows > 32)) {  // (group >= 32: every multi-row sequence already has > 32 rows)
       tk.rows_lo = first_tile_rows;
       tk.rows_hi = 33;
       rc = launch_attn_tile(tk, a->dtype, max_rows < 32 ? max_rows : 32, st);
@@ -944,7 +951,7 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
   hip_clear_error();
   const int64_t grid = (int64_t)a->n_tokens * pl.nhgb * pl.n_chunks * pl.n_splits;
   if (grid <= 0 || grid > 0x7fffffffLL) return SLM_ERR_INVALID_ARG;
-  if (!(tile_used && dec_tile)) {  // (every sequence has >= group rows: nothing left for it then)
+  if (!(tile_used && (dec_tile || !token_rows_possible))) {  // (every sequence has >= group rows: nothing left for it then)
     if (a->dtype == SLM_BF16)
       dispatch_lpr<bf16_tag>(kp, pl, grid, st);
     else
