@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
       uint32_t seen;
       do {  // arrival check: by now (one tile later) it passes at the first look
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(caddr) : "memory");
-      } while (__builtin_amdgcn_readfirstlane(seen) < target);
+      } while ((uint32_t)__builtin_amdgcn_readfirstlane(seen) < target);
     }
     stamp(6 + 4 * (tp < 0 ? 0 : tp));
     f32x4 pv4[MT][RPW == 4 ? NW : 1];
