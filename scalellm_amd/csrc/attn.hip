@@ -46,7 +46,13 @@ __device__ __forceinline__ u32x4 ld16(const void* p) {
 // FX: the rare score transforms (logits soft-cap and/or alibi) are compiled in; the FX = false fast
 // path folds the softmax scale into one fma per score, like the reference's exp2(x*s - max*s)
 // (common/online_softmax.cuh:39-162).
-template <typename T, int LPR, int GC, int U, bool NT, bool FX>
+// W (round 4): 16-byte chunks of a K / V row per lane.  W = 1: LPR lanes x 8 dims cover the row.  W = 2: a
+// lane owns TWO chunks (dims [8 sub, 8 sub + 8) and [8 LPR + 8 sub, ...)), so half as many lanes share a row:
+// the 16-lane reduction of every score becomes an 8-lane one, and the softmax arithmetic every lane of a
+// group repeats for its rows is done for half as many rows per lane -- the same bytes in flight (U rows x W
+// chunks), ~37 % fewer VALU instructions per KV byte.  The stream kernel was at the HBM rate already; what
+// this buys is ISSUE SLOTS for the int4 GEMMs that share the SIMDs in the two-lane decode step.
+template <typename T, int LPR, int GC, int U, bool NT, bool FX, int W = 1>
 __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int* tbl = reinterpret_cast<int*>(smem);
@@ -102,12 +108,12 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
   const bool bal = p.bal && p.q_cu[p.batch] == p.batch;
   int bal_g = 0, bal_g1 = 0, bal_Q = 1;  // (all < 2^31: kv_cu is int32)
   if (bal) {
-    const int W = p.kv_cu[p.batch];
-    bal_Q = attn_bal_q(p, W);
+    const int Wtot = p.kv_cu[p.batch];
+    bal_Q = attn_bal_q(p, Wtot);
     const int64_t g64 = (int64_t)(tok * p.n_splits + split) * bal_Q;
-    if (g64 >= (int64_t)W) return;
+    if (g64 >= (int64_t)Wtot) return;
     bal_g = (int)g64;
-    bal_g1 = W - bal_g > bal_Q ? bal_g + bal_Q : W;
+    bal_g1 = Wtot - bal_g > bal_Q ? bal_g + bal_Q : Wtot;
     int lo_b = 0, hi_b = p.batch;  // sequence holding token g: kv_cu[b] <= g < kv_cu[b + 1]
     while (lo_b < hi_b) {
       const int mid = (lo_b + hi_b) >> 1;
@@ -137,6 +143,7 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
 
   const int kvh = (((hgb << p.hgw_shift) + hgw) << p.hpw_shift) + hsub;
   const int qh0_lane = kvh * p.group + chunk * GC;
+  constexpr int CH = 16 * LPR;              // bytes between the W chunks of a lane (W = 2 needs head_dim = 16 LPR)
   const bool act = (sub * 8) < p.head_dim;  // head_dim < 8*LPR leaves idle lanes (D = 40, 96)
   const int sub_ld = act ? sub : 0;  // idle lanes (q = 0) re-read dims 0..7: finite, never stored
   const char* kbase = reinterpret_cast<const char*>(p.kc) + 2 * ((int64_t)kvh * p.k_hs + sub_ld * 8);
@@ -188,33 +195,35 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
     s_hi = min(hi, s_lo + per);
   }
 
-  // q fragment: GC heads x 8 dims (packed pairs)
-  uint32_t qv[GC][4];
+  // q fragment: GC heads x W chunks x 8 dims (packed pairs)
+  uint32_t qv[GC][4 * W];
 #pragma unroll
   for (int h = 0; h < GC; ++h) {
-    u32x4 t = {0u, 0u, 0u, 0u};
-    if (act) {
-      const T* qp = reinterpret_cast<const T*>(p.q);
-      (void)qp;
-      const char* ptr = reinterpret_cast<const char*>(p.q) +
-                        2 * ((int64_t)tok_p * p.q_ts + (int64_t)(qh0_lane + h) * p.q_hs + sub * 8);
-      t = *reinterpret_cast<const u32x4*>(ptr);
+#pragma unroll
+    for (int c = 0; c < W; ++c) {
+      u32x4 t = {0u, 0u, 0u, 0u};
+      if (act) {
+        const char* ptr = reinterpret_cast<const char*>(p.q) + c * CH +
+                          2 * ((int64_t)tok_p * p.q_ts + (int64_t)(qh0_lane + h) * p.q_hs + sub * 8);
+        t = *reinterpret_cast<const u32x4*>(ptr);
+      }
+      qv[h][4 * c + 0] = t.x; qv[h][4 * c + 1] = t.y; qv[h][4 * c + 2] = t.z; qv[h][4 * c + 3] = t.w;
     }
-    qv[h][0] = t.x; qv[h][1] = t.y; qv[h][2] = t.z; qv[h][3] = t.w;
   }
 
-  float m[GC], l[GC], o[GC][8];
+  constexpr int OD = 8 * W;  // output dims per lane and head
+  float m[GC], l[GC], o[GC][OD];
 #pragma unroll
   for (int h = 0; h < GC; ++h) {
     m[h] = ATTN_M_INIT;
     l[h] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[h][j] = 0.f;
+    for (int j = 0; j < OD; ++j) o[h][j] = 0.f;
   }
 
   const int bcu0 = p.bcu[b];
 
-  u32x4 kr[U], vr[U];
+  u32x4 kr[U][W], vr[U][W];
 
   for (int c_lo = s_lo; c_lo < s_hi;) {
     const int blk0 = c_lo >> p.block_shift;
@@ -243,10 +252,23 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
       }
     };
     slots_for(0);
+    // (W == 1 keeps its statements exactly as they were: the loop's schedule -- counted vmcnt waits, the
+    // position of every load -- is what the 6.9 TB/s rest on, and hipcc re-derives it from the source shape)
+    if constexpr (W == 1) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) kr[u] = ld16<NT>(kbase + (uint64_t)(uint32_t)slot_n[u] * k_sb);
+      for (int u = 0; u < U; ++u) kr[u][0] = ld16<NT>(kbase + (uint64_t)(uint32_t)slot_n[u] * k_sb);
 #pragma unroll
-    for (int u = 0; u < U; ++u) vr[u] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u] * v_sb);
+      for (int u = 0; u < U; ++u) vr[u][0] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u] * v_sb);
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int c = 0; c < W; ++c) kr[u][c] = ld16<NT>(kbase + (uint64_t)(uint32_t)slot_n[u] * k_sb + c * CH);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int c = 0; c < W; ++c) vr[u][c] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u] * v_sb + c * CH);
+    }
     // compiler fence: keeps hipcc from sinking the prologue / next-batch loads into the
     // consuming iteration (which would shorten the prefetch distance to < 1 batch)
     asm volatile("" ::: "memory");
@@ -256,16 +278,31 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
       float s[U][GC];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const u32x4 kk = kr[u];
+        if constexpr (W == 1) {
+          const u32x4 kk = kr[u][0];
 #pragma unroll
-        for (int h = 0; h < GC; ++h) {
-          float a = dot2<T>(kk.x, qv[h][0], 0.f);
-          a = dot2<T>(kk.y, qv[h][1], a);
-          a = dot2<T>(kk.z, qv[h][2], a);
-          s[u][h] = dot2<T>(kk.w, qv[h][3], a);
+          for (int h = 0; h < GC; ++h) {
+            float a = dot2<T>(kk.x, qv[h][0], 0.f);
+            a = dot2<T>(kk.y, qv[h][1], a);
+            a = dot2<T>(kk.z, qv[h][2], a);
+            s[u][h] = dot2<T>(kk.w, qv[h][3], a);
+          }
+          kr[u][0] = ld16<NT>(kbase + (uint64_t)(uint32_t)slot_n[u] * k_sb);
+        } else {
+#pragma unroll
+          for (int c = 0; c < W; ++c) {
+            const u32x4 kk = kr[u][c];
+#pragma unroll
+            for (int h = 0; h < GC; ++h) {
+              float a = dot2<T>(kk.x, qv[h][4 * c + 0], c == 0 ? 0.f : s[u][h]);
+              a = dot2<T>(kk.y, qv[h][4 * c + 1], a);
+              a = dot2<T>(kk.z, qv[h][4 * c + 2], a);
+              s[u][h] = dot2<T>(kk.w, qv[h][4 * c + 3], a);
+            }
+            kr[u][c] = ld16<NT>(kbase + (uint64_t)(uint32_t)slot_n[u] * k_sb + c * CH);
+          }
         }
-        kr[u] = ld16<NT>(kbase + (uint64_t)(uint32_t)slot_n[u] * k_sb);
-        __builtin_amdgcn_sched_barrier(0);  // pin: next-batch K load issues right here
+        __builtin_amdgcn_sched_barrier(0);  // pin: next-batch K load(s) issue right here
       }
       // 16-lane all-reduce of the U*GC partial sums, STEP-major: the U*GC independent chains are
       // interleaved so the VALU-write -> DPP-read wait states are filled with useful work
@@ -296,7 +333,7 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
         m[h] = mn;
         l[h] *= alpha;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[h][j] *= alpha;
+        for (int j = 0; j < OD; ++j) o[h][j] *= alpha;
       }
       float pr[U][GC];
 #pragma unroll
@@ -311,40 +348,67 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
         // (row a, row b) pairs per dim, P is rounded to T (as every MFMA flash-attention does)
 #pragma unroll
         for (int u = 0; u < U; u += 2) {
-          const u32x4 va = vr[u], vb = vr[u + 1];
+          if constexpr (W == 1) {
+            const u32x4 va = vr[u][0], vb = vr[u + 1][0];
+            uint32_t pp[GC];
+#pragma unroll
+            for (int h = 0; h < GC; ++h) pp[h] = pack2<T>(pr[u][h], pr[u + 1][h]);
+            const uint32_t wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t lo = __builtin_amdgcn_perm(wb[j], wa[j], 0x05040100u);
+              const uint32_t hi = __builtin_amdgcn_perm(wb[j], wa[j], 0x07060302u);
+#pragma unroll
+              for (int h = 0; h < GC; ++h) {
+                o[h][2 * j] = dot2<T>(lo, pp[h], o[h][2 * j]);
+                o[h][2 * j + 1] = dot2<T>(hi, pp[h], o[h][2 * j + 1]);
+              }
+            }
+            vr[u][0] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u] * v_sb);
+            vr[u + 1][0] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u + 1] * v_sb);
+            __builtin_amdgcn_sched_barrier(0);  // pin: next-batch V loads issue right here
+            continue;
+          }
           uint32_t pp[GC];
 #pragma unroll
           for (int h = 0; h < GC; ++h) pp[h] = pack2<T>(pr[u][h], pr[u + 1][h]);
-          const uint32_t wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t lo = __builtin_amdgcn_perm(wb[j], wa[j], 0x05040100u);
-            const uint32_t hi = __builtin_amdgcn_perm(wb[j], wa[j], 0x07060302u);
+          for (int c = 0; c < W; ++c) {
+            const u32x4 va = vr[u][c], vb = vr[u + 1][c];
+            const uint32_t wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
-            for (int h = 0; h < GC; ++h) {
-              o[h][2 * j] = dot2<T>(lo, pp[h], o[h][2 * j]);
-              o[h][2 * j + 1] = dot2<T>(hi, pp[h], o[h][2 * j + 1]);
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t lo = __builtin_amdgcn_perm(wb[j], wa[j], 0x05040100u);
+              const uint32_t hi = __builtin_amdgcn_perm(wb[j], wa[j], 0x07060302u);
+#pragma unroll
+              for (int h = 0; h < GC; ++h) {
+                o[h][8 * c + 2 * j] = dot2<T>(lo, pp[h], o[h][8 * c + 2 * j]);
+                o[h][8 * c + 2 * j + 1] = dot2<T>(hi, pp[h], o[h][8 * c + 2 * j + 1]);
+              }
             }
+            vr[u][c] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u] * v_sb + c * CH);
+            vr[u + 1][c] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u + 1] * v_sb + c * CH);
           }
-          vr[u] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u] * v_sb);
-          vr[u + 1] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u + 1] * v_sb);
           __builtin_amdgcn_sched_barrier(0);  // pin: next-batch V loads issue right here
         }
       } else {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const u32x4 vv = vr[u];
-          float vf[8];
-          vf[0] = lo_f32<T>(vv.x); vf[1] = hi_f32<T>(vv.x);
-          vf[2] = lo_f32<T>(vv.y); vf[3] = hi_f32<T>(vv.y);
-          vf[4] = lo_f32<T>(vv.z); vf[5] = hi_f32<T>(vv.z);
-          vf[6] = lo_f32<T>(vv.w); vf[7] = hi_f32<T>(vv.w);
 #pragma unroll
-          for (int h = 0; h < GC; ++h) {
+          for (int c = 0; c < W; ++c) {
+            const u32x4 vv = vr[u][c];
+            float vf[8];
+            vf[0] = lo_f32<T>(vv.x); vf[1] = hi_f32<T>(vv.x);
+            vf[2] = lo_f32<T>(vv.y); vf[3] = hi_f32<T>(vv.y);
+            vf[4] = lo_f32<T>(vv.z); vf[5] = hi_f32<T>(vv.z);
+            vf[6] = lo_f32<T>(vv.w); vf[7] = hi_f32<T>(vv.w);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[h][j] = fmaf(pr[u][h], vf[j], o[h][j]);
+            for (int h = 0; h < GC; ++h) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) o[h][8 * c + j] = fmaf(pr[u][h], vf[j], o[h][8 * c + j]);
+            }
+            vr[u][c] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u] * v_sb + c * CH);
           }
-          vr[u] = ld16<NT>(vbase + (uint64_t)(uint32_t)slot_n[u] * v_sb);
           __builtin_amdgcn_sched_barrier(0);  // pin: next-batch V load issues right here
         }
       }
@@ -359,7 +423,7 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
   }
 
   // ---- merge the row-phase lane groups of this wave (same kv head, different rows) ----
-  auto merge = [&](const float (&om)[GC], const float (&ol)[GC], const float (&oo)[GC][8]) {
+  auto merge = [&](const float (&om)[GC], const float (&ol)[GC], const float (&oo)[GC][OD]) {
 #pragma unroll
     for (int h = 0; h < GC; ++h) {
       const float mn = fmaxf(m[h], om[h]);
@@ -368,44 +432,45 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
       m[h] = mn;
       l[h] = l[h] * fa + ol[h] * fb;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[h][j] = o[h][j] * fa + oo[h][j] * fb;
+      for (int j = 0; j < OD; ++j) o[h][j] = o[h][j] * fa + oo[h][j] * fb;
     }
   };
   for (int d = LPR << p.hpw_shift; d < 64; d <<= 1) {
-    float om[GC], ol[GC], oo[GC][8];
+    float om[GC], ol[GC], oo[GC][OD];
 #pragma unroll
     for (int h = 0; h < GC; ++h) {
       om[h] = __shfl_xor(m[h], d, 64);
       ol[h] = __shfl_xor(l[h], d, 64);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) oo[h][j] = __shfl_xor(o[h][j], d, 64);
+      for (int j = 0; j < OD; ++j) oo[h][j] = __shfl_xor(o[h][j], d, 64);
     }
     merge(om, ol, oo);
   }
 
   // ---- merge row-phase waves through LDS (sequential rounds; once per workgroup) ----
-  constexpr int NF = 10 * GC;  // floats of state per lane
+  constexpr int SF = 2 + OD;    // floats of state per lane and head
+  constexpr int NF = SF * GC;   // floats of state per lane
   float* my = xch + (size_t)hgw * NF * 64;
   for (int r = 1; r < RP; ++r) {
     __syncthreads();
     if (rp == r) {
 #pragma unroll
       for (int h = 0; h < GC; ++h) {
-        my[(h * 10 + 0) * 64 + lane] = m[h];
-        my[(h * 10 + 1) * 64 + lane] = l[h];
+        my[(h * SF + 0) * 64 + lane] = m[h];
+        my[(h * SF + 1) * 64 + lane] = l[h];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) my[(h * 10 + 2 + j) * 64 + lane] = o[h][j];
+        for (int j = 0; j < OD; ++j) my[(h * SF + 2 + j) * 64 + lane] = o[h][j];
       }
     }
     __syncthreads();
     if (rp == 0) {
-      float om[GC], ol[GC], oo[GC][8];
+      float om[GC], ol[GC], oo[GC][OD];
 #pragma unroll
       for (int h = 0; h < GC; ++h) {
-        om[h] = my[(h * 10 + 0) * 64 + lane];
-        ol[h] = my[(h * 10 + 1) * 64 + lane];
+        om[h] = my[(h * SF + 0) * 64 + lane];
+        ol[h] = my[(h * SF + 1) * 64 + lane];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) oo[h][j] = my[(h * 10 + 2 + j) * 64 + lane];
+        for (int j = 0; j < OD; ++j) oo[h][j] = my[(h * SF + 2 + j) * 64 + lane];
       }
       merge(om, ol, oo);
     }
@@ -420,22 +485,28 @@ __global__ void __launch_bounds__(512) attn_token_kernel(const AttnKParams p) {
 #pragma unroll
       for (int h = 0; h < GC; ++h) {
         const float inv = l[h] > 0.f ? 1.0f / l[h] : 0.f;
-        u32x4 r;
-        r.x = pack2<T>(o[h][0] * inv, o[h][1] * inv);
-        r.y = pack2<T>(o[h][2] * inv, o[h][3] * inv);
-        r.z = pack2<T>(o[h][4] * inv, o[h][5] * inv);
-        r.w = pack2<T>(o[h][6] * inv, o[h][7] * inv);
-        char* ptr = reinterpret_cast<char*>(p.out) +
-                    2 * ((int64_t)tok_p * p.o_ts + (int64_t)(qh0 + h) * p.o_hs + sub * 8);
-        *reinterpret_cast<u32x4*>(ptr) = r;
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          u32x4 r;
+          r.x = pack2<T>(o[h][8 * c + 0] * inv, o[h][8 * c + 1] * inv);
+          r.y = pack2<T>(o[h][8 * c + 2] * inv, o[h][8 * c + 3] * inv);
+          r.z = pack2<T>(o[h][8 * c + 4] * inv, o[h][8 * c + 5] * inv);
+          r.w = pack2<T>(o[h][8 * c + 6] * inv, o[h][8 * c + 7] * inv);
+          char* ptr = reinterpret_cast<char*>(p.out) + c * CH +
+                      2 * ((int64_t)tok_p * p.o_ts + (int64_t)(qh0 + h) * p.o_hs + sub * 8);
+          *reinterpret_cast<u32x4*>(ptr) = r;
+        }
       }
     } else {
 #pragma unroll
       for (int h = 0; h < GC; ++h) {
         const int64_t pi = ((int64_t)tok_p * p.n_heads + (qh0 + h)) * p.part_slots + part_idx;
-        float* op = p.o_part + pi * p.head_dim + sub * 8;
-        *reinterpret_cast<f32x4*>(op) = f32x4{o[h][0], o[h][1], o[h][2], o[h][3]};
-        *reinterpret_cast<f32x4*>(op + 4) = f32x4{o[h][4], o[h][5], o[h][6], o[h][7]};
+#pragma unroll
+        for (int c = 0; c < W; ++c) {
+          float* op = p.o_part + pi * p.head_dim + c * (CH / 2) + sub * 8;
+          *reinterpret_cast<f32x4*>(op) = f32x4{o[h][8 * c + 0], o[h][8 * c + 1], o[h][8 * c + 2], o[h][8 * c + 3]};
+          *reinterpret_cast<f32x4*>(op + 4) = f32x4{o[h][8 * c + 4], o[h][8 * c + 5], o[h][8 * c + 6], o[h][8 * c + 7]};
+        }
         if (sub == 0) {
           p.ml_part[pi * 2 + 0] = m[h];
           p.ml_part[pi * 2 + 1] = l[h];
@@ -584,7 +655,7 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(const AttnKParams p, 
 
 // ------------------------------- host side ------------------------------------------
 struct AttnPlan {
-  int lpr, gc, hpw_shift, hgw_shift, nhgb, n_chunks, nw, n_splits, u;
+  int lpr, gc, hpw_shift, hgw_shift, nhgb, n_chunks, nw, n_splits, u, w;
   bool nt;
   size_t lds_bytes;
   // balanced pure-decode partition (AttnKParams::bal): partial slots per (token, head) and the
@@ -619,8 +690,24 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
     return SLM_ERR_INVALID_ARG;
   const int D = a->head_dim, G = a->n_heads / a->n_kv_heads;
   pl->lpr = D <= 32 ? 4 : D <= 64 ? 8 : D <= 128 ? 16 : 32;
-  const int upw = 64 / pl->lpr;
   pl->gc = (G % 8 == 0) ? 8 : (G % 4 == 0) ? 4 : (G % 2 == 0) ? 2 : 1;
+  // Two 16-byte chunks of a row per lane (attn_token_kernel W = 2): head_dim 128 on 8 lanes per row, plain
+  // softmax only (the soft-cap / alibi instantiation keeps one chunk), <= 4 query heads per lane (8 x 16 output
+  // dims do not fit the registers).  Measured (profiles/r04_attn_w2.jsonl): alone the two forms stream at the same
+  // rate from 64 sequences up with >= 4 KV heads per rank (32 / 8 heads, bs 256: 638 vs 642 us; 16 / 4: 327 vs 338)
+  // and W = 2 loses below that (bs 1: 15.4 vs 13.3 us; one KV head, bs 64: 32.1 vs 30.3) -- but it needs 19 % fewer
+  // instructions per KV byte, and in the two-lane decode step those issue slots go to the other lane's GEMMs
+  // (qkv / o / gate_up 82 -> 58 us next to the stream): bs 128 14.09 -> 13.83 ms, bs 256 24.09 -> 23.85.
+  // SLM_ATTN_W: 1 / 2 force a form.
+  pl->w = 1;
+  if (D == 128 && pl->gc <= 4 && a->logits_soft_cap <= 0.f && a->alibi_slopes == nullptr) {
+    const int w_knob = tune_get(TUNE_ATTN_W, 0);
+    if (w_knob == 2 || (w_knob != 1 && a->n_tokens >= 64 && a->n_kv_heads >= 4)) {
+      pl->w = 2;
+      pl->lpr = 8;
+    }
+  }
+  const int upw = 64 / pl->lpr;
   pl->n_chunks = G / pl->gc;
   int hpw = 1;
   while (hpw * 2 <= upw && a->n_kv_heads % (hpw * 2) == 0) hpw *= 2;
@@ -637,7 +724,7 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
   // workgroup, ~256 workgroups per launch, >= 64 KV rows per split.
   pl->nw = tune_get(TUNE_ATTN_NW, 4);
   if (pl->nw != 1 && pl->nw != 2 && pl->nw != 4 && pl->nw != 8) pl->nw = 4;
-  const size_t state = (size_t)10 * pl->gc * 64 * sizeof(float);
+  const size_t state = (size_t)(2 + 8 * pl->w) * pl->gc * 64 * sizeof(float);
   const int64_t target_wgs = 256;
   const int64_t max_by_len = (a->max_kv_len > 64 ? a->max_kv_len : 64) / 64;
   int forced_splits = a->num_splits > 0 ? a->num_splits : tune_get(TUNE_ATTN_SPLITS, 0);
@@ -655,7 +742,7 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
     // LDS: table + HGW x per-wave exchange state, kept under the 64 KiB default dynamic limit
     hgw = 1;
     while (hgw * 2 <= pl->nw && hgw * 2 <= hgw_cap && nhg % (hgw * 2) == 0 &&
-           (size_t)(hgw * 2) * state <= 48 * 1024)
+           (size_t)(hgw * 2) * state <= (pl->w == 2 ? 96 : 48) * 1024)  // (W = 2: 18 KiB per head group, opted in at launch)
       hgw *= 2;
     base = (int64_t)a->n_tokens * (nhg / hgw) * pl->n_chunks;
     int64_t want = (target_wgs + base - 1) / (base > 0 ? base : 1);
@@ -781,7 +868,7 @@ static int plan_attn(const slm_attn_args* a, AttnPlan* pl) {
     pl->bal_qmin = (int)(qmin > 1 ? qmin : 1);
     if (pl->n_splits >= slots) pl->n_splits = slots - 1;  // P = n_tokens * n_splits workgroups per head group
   }
-  pl->u = tune_get(TUNE_ATTN_U, 4);
+  pl->u = tune_get(TUNE_ATTN_U, pl->w == 2 ? 2 : 4);  // (two chunks: the same bytes in flight with half the rows)
   if (pl->u != 2 && pl->u != 4) pl->u = 4;
   pl->nt = tune_get(TUNE_ATTN_NT, a->max_q_len <= 1 ? 1 : 0) != 0;
   return SLM_OK;
@@ -793,6 +880,25 @@ static void launch_token_kernel(const AttnKParams& kp, const AttnPlan& pl, int64
   const dim3 g((unsigned)grid), blk(pl.nw * 64);
 #define SLM_LAUNCH(UU, NTT, SCC)                                                                \
   hipLaunchKernelGGL((attn_token_kernel<T, LPR, GC, UU, NTT, SCC>), g, blk, pl.lds_bytes, st, kp)
+  if constexpr (LPR == 8 && GC <= 4) {
+    if (pl.w == 2) {  // (plan_attn: plain softmax, head_dim 128, <= 4 query heads per lane)
+#define SLM_LAUNCH_W2(UU, NTT)                                                                             \
+  do {                                                                                                     \
+    auto kfn = attn_token_kernel<T, LPR, GC, UU, NTT, false, 2>;                                           \
+    static bool opted = false; /* > 64 KiB of dynamic LDS has to be opted into once per kernel */          \
+    if (!opted) {                                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                128 * 1024);                                                               \
+      opted = true;                                                                                        \
+    }                                                                                                      \
+    hipLaunchKernelGGL(kfn, g, blk, pl.lds_bytes, st, kp);                                                 \
+  } while (0)
+      if (pl.u == 2) { if (pl.nt) SLM_LAUNCH_W2(2, true); else SLM_LAUNCH_W2(2, false); }
+      else { if (pl.nt) SLM_LAUNCH_W2(4, true); else SLM_LAUNCH_W2(4, false); }
+#undef SLM_LAUNCH_W2
+      return;
+    }
+  }
   if (kp.softcap > 0.f || kp.alibi != nullptr) {
     SLM_LAUNCH(2, false, true);  // soft-cap / alibi models: one tuned shape
   } else if (pl.u == 2) {

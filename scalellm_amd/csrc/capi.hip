@@ -13,7 +13,7 @@ namespace {
 const char* const kTuneNames[TUNE_COUNT] = {
     "SLM_ATTN_NW",          "SLM_ATTN_SPLITS",      "SLM_ATTN_HGW",     "SLM_ATTN_TILE",
     "SLM_ATTN_TILE_SPLITS", "SLM_ATTN_TILE_PF",     "SLM_ATTN_U",       "SLM_ATTN_NT",
-    "SLM_ATTN_TILE_DECODE", "SLM_ATTN_BAL",         "SLM_ATTN_PRIO",
+    "SLM_ATTN_TILE_DECODE", "SLM_ATTN_BAL",         "SLM_ATTN_W",       "SLM_ATTN_PRIO",
     "SLM_W4_GEMV",          "SLM_W4_GEMV_KS",   "SLM_W4_SMALL",
     "SLM_W4_MT",            "SLM_W4_MT_WIDE",       "SLM_W4_NTW",           "SLM_W4_PC",        "SLM_W4_SPLITK",
     "SLM_W4_POST",

@@ -21,6 +21,7 @@ enum TuneKey : int {
   TUNE_ATTN_NT,           // SLM_ATTN_NT           non-temporal KV loads on/off
   TUNE_ATTN_TILE_DECODE,  // SLM_ATTN_TILE_DECODE  min GQA group at which q_len = 1 goes to the tile kernel (default 8, 0 = never)
   TUNE_ATTN_BAL,          // SLM_ATTN_BAL          0 = classic per-sequence split-KV for pure decode (no balanced partition)
+  TUNE_ATTN_W,            // SLM_ATTN_W            16-byte chunks of a K / V row per lane in the decode stream kernel: 1 / 2 force a form (default: by batch size and KV heads)
   TUNE_ATTN_PRIO,         // SLM_ATTN_PRIO         0 = the decode stream kernel does not raise its wave priority (default 1: s_setprio 3)
   TUNE_W4_GEMV,           // SLM_W4_GEMV           0 off, 1 = M == 1 only, 2 = M <= 4
   TUNE_W4_GEMV_KS,        // SLM_W4_GEMV_KS        forced K slices per GEMV workgroup (1/2/4/8)

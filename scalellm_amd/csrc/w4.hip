@@ -547,8 +547,12 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
     // BM = 128 when its tiles alone fill the chip, or when K is deep AND there are enough column
     // tiles to spread (a deep, very narrow shard -- 70B TP=8 qkv: 8192 x 1280 -- runs 20 % faster
     // on twice as many BM = 64 tiles: 22.0 -> 17.7 us)
+    // (round 4: the deep-K rule starts at 64 tiles, not 32.  Llama-3-8B's down_proj -- 14336 x 4096, 32 tiles --
+    // is 3 % faster alone on BM = 128 (33.0 vs 34.1 us at M = 128), but in the two-lane decode step its 64 KiB,
+    // ~200-VGPR workgroups share a CU badly with the attention stream's: 79 -> 135 us per call once the stream
+    // kernel keeps two row chunks per lane, 58 us on BM = 64 tiles like the other three layers)
     const int64_t tiles4 = ((a->M + 127) / 128) * ((a->N + 127) / 128);
-    mt = (tiles4 >= 256 || (a->K >= 8192 && tiles4 >= 32)) ? 4 : 2;
+    mt = (tiles4 >= 256 || (a->K >= 8192 && tiles4 >= 64)) ? 4 : 2;
   } else {
     // M > 128: the wave-specialised 256 x 128 kernel (w4_ws.hip) when its tiles alone keep about
     // half of the 256 CUs busy (measured: 0.89-1.06 PFLOP/s vs 0.74-0.86 for the single-role
