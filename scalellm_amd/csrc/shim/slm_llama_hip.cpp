@@ -167,7 +167,9 @@ int64_t LlamaForCausalLMHip::lane_split(int64_t T, const InputParameters& p) con
   if (!opt_.fused || opt_.decode_lanes == 0 || parallel_args_.world_size() != 1) return 0;
   if (p.q_max_seq_len != 1 || T != n_seqs || T < 64) return 0;
   if (opt_.decode_lanes < 0) {
-    if (!((96 <= T && T <= 160) || (232 <= T && T <= 256))) return 0;
+    if (!(96 <= T && T <= 256)) return 0;
+    // ... long sequences (>= 12 MiB of K + V each) ...
+    if (4 * n_kv_heads_ * args_.head_dim * static_cast<int64_t>(p.kv_max_seq_len) < (int64_t(12) << 20)) return 0;
     // ... and only while the KV stream dominates the layer (>= 8 x the layer's weight bytes)
     const int64_t kv_bytes = 4 * n_kv_heads_ * args_.head_dim * T * static_cast<int64_t>(p.kv_max_seq_len);
     const int64_t tp = parallel_args_.world_size();

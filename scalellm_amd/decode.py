@@ -120,22 +120,27 @@ def two_lane_split(shape: "LlamaShape", n_heads: int, n_kv_heads: int, world_siz
     replays on, model_runner.cpp:112-140, under which q_cu_seq_lens is the identity), and -- lanes_min:
     -1 = auto, 0 = never, N = every such batch of >= N tokens (tests, sweeps; SLM_DECODE_LANES).
 
-    auto: where two lanes were measured faster on one MI355X (Llama-3-8B shapes, 4 k context,
-    profiles/r04_lanes_sweep.jsonl): T = 96 +3.2 %, 128 +6.4 %, 160 +1.4 %, 256 +3.4..5.4 %; slower at
-    192 (-3.7 %: 96-sequence attention launches fill the CUs badly), 224 (-7 %), 320 (-6 %), 384 (-2 %):
-    halves beyond 128 rows put BOTH lanes' GEMMs past the M = 129 tile step, 2 x 157 us instead of one
-    175-250 us launch set; no change at 64.  And only while the KV stream dominates the layer: the
-    lanes hide GEMM time under attention time, and with little attention to hide under they only pay
-    their costs.  Measured: 8B bs 256 at kv_len 4096 / 2048 / 1024 / 512 = 36 / 18 / 9 / 4.5 x the layer's
-    weight bytes: +7 / +3 / +2 / -5 %; bs 128 at 1024 (4.5 x) -1 %; Llama-3-70B shapes bs 128 at 4096
-    (5 x) -7 %."""
+    auto: where two lanes were measured faster on one MI355X (Llama-3-8B shapes; profiles/r04_lanes_sweep.jsonl
+    and, with the stream kernel's two-chunk form, r04_lanes_sweep_w2.jsonl), all three of:
+      * 96 <= T <= 256.  At 4 k context, ms per step one lane -> two: T = 96 12.44 -> 11.91 (+4 %), 160 19.34 ->
+        18.17 (+6 %), 192 21.55 -> 20.17 (+7 %), 224 24.92 -> 22.23 (+12 %), 256 26.10 -> 23.78 (+10 %); 64 the same;
+        320 (-1 %) and 384 (-3 %) lose: halves beyond 128 rows put BOTH lanes' GEMMs past the M = 129 tile step.
+        (Before the two-chunk stream kernel freed issue slots for the co-running GEMMs, 192 and 224 lost.)
+      * long sequences: K + V bytes per sequence >= 12 MiB (3 k tokens of 8 KV heads x 128).  The halves' attention
+        launches have to be long against the fixed cost of a launch and against the GEMM chain they hide: at T = 256,
+        context 4096 / 2048 / 1024 / 512: +10 / -4 / +2 / -5 %; T = 128: +4 / 0 / 0 / -6 %; T = 192 at 1024: -12 %.
+      * the KV stream dominates the layer's weights (>= 8 x their bytes): Llama-3-70B shapes, T = 128 at 4096
+        (5 x): -4...-7 %.
+    """
     T = n_tokens
     if lanes_min == 0 or world_size != 1:
         return 0
     if q_max_seq_len != 1 or T != n_seqs or T < 64:
         return 0
     if lanes_min < 0:
-        if not (96 <= T <= 160 or 232 <= T <= 256):
+        if not 96 <= T <= 256:
+            return 0
+        if 4 * n_kv_heads * shape.head_dim * kv_max_seq_len < (12 << 20):
             return 0
         kv_bytes = 4 * n_kv_heads * shape.head_dim * T * kv_max_seq_len
         w_bytes = (shape.hidden * (n_heads + 2 * n_kv_heads) * shape.head_dim +

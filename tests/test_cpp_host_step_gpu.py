@@ -32,7 +32,7 @@ def cpp_params(shim, p):
     return cpp_host.cpp_params(p)
 
 
-def cpp_model_from(shim, step, block_size, max_tokens, fused=True, lanes=-1, quant="awq"):
+def cpp_model_from(shim, step, block_size, max_tokens, fused=True, lanes=64, quant="awq"):
     """slm::LlamaForCausalLMHip over the Python step's checkpoint tensors, KV caches and RoPE table."""
     from scalellm_amd import cpp_host
     return cpp_host.from_decode_step(step, block_size, max_tokens, fused=fused, lanes=lanes)
@@ -43,6 +43,9 @@ def _step(quant, max_tokens, n_blocks, B, seed=2):
     shape = LlamaShape.tiny()
     step = LlamaDecodeStep(shape, max_tokens, n_blocks, B, quant_method=quant, group_size=128, dtype=torch.bfloat16,
                            device=DEV, seed=seed, keep_checkpoint=True)
+    # two lanes for every pure-decode batch of >= 64 tokens, on both hosts (the automatic rule wants 12 MiB of
+    # K + V per sequence -- not what a tiny test model has; the rule itself: tests/test_host_logic_cpu.py)
+    step.lanes_min = 64
     g = torch.Generator(device=DEV).manual_seed(seed + 50)
     for L in step.layers:
         L["kv"].key_cache.normal_(generator=g)

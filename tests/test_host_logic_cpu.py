@@ -192,13 +192,13 @@ def test_two_lane_policy_table():
     def auto(T, kv=4096, shape=s8, heads=(32, 8), world=1, n_seqs=None, q_max=1):
         return two_lane_split(shape, heads[0], heads[1], world, -1, T, T if n_seqs is None else n_seqs, q_max, kv)
 
-    # measured window at 4 k context (profiles/r04_lanes_sweep.jsonl); lane 0 gets a multiple of 32 rows
-    assert [auto(T) for T in (32, 64, 96, 128, 160, 192, 224, 232, 256, 257, 320, 384)] == \
-        [0, 0, 64, 64, 96, 0, 0, 128, 128, 0, 0, 0]
-    # the KV stream has to dominate the layer's weight bytes (>= 8 x)
-    assert auto(256, kv=2048) == 128 and auto(256, kv=1024) == 128 and auto(256, kv=512) == 0
-    assert auto(128, kv=1024) == 0
-    assert auto(128, shape=s70, heads=(64, 8)) == 0
+    # measured window at 4 k context (profiles/r04_lanes_sweep_w2.jsonl); lane 0 gets a multiple of 32 rows
+    assert [auto(T) for T in (32, 64, 95, 96, 128, 160, 192, 224, 256, 257, 320, 384)] == \
+        [0, 0, 0, 64, 64, 96, 96, 128, 128, 0, 0, 0]
+    # long sequences only (>= 12 MiB of K + V each: 3072 tokens of 8 x 128) ...
+    assert auto(256, kv=3072) == 128 and auto(256, kv=3071) == 0 and auto(256, kv=2048) == 0 and auto(128, kv=1024) == 0
+    # ... and the KV stream has to dominate the layer's weight bytes (>= 8 x): not on the 70B shapes at bs 128
+    assert auto(128, shape=s70, heads=(64, 8)) == 0 and auto(256, shape=s70, heads=(64, 8), kv=8192) == 128
     # never across ranks, never for batches that are not one token per sequence
     assert auto(256, world=8, heads=(4, 1)) == 0
     assert auto(256, n_seqs=100) == 0 and auto(256, n_seqs=64, q_max=4) == 0
