@@ -39,7 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from scalellm_amd import kernels  # noqa: E402
-from scalellm_amd.decode import LlamaDecodeStep, LlamaShape, make_decode_inputs  # noqa: E402
+from scalellm_amd.decode import LlamaDecodeStep, LlamaShape, make_batch_inputs, make_decode_inputs  # noqa: E402
 from scalellm_amd.model_parallel import ParallelArgs, ProcessGroup  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
@@ -56,11 +56,31 @@ def _rccl_version():
 
 
 def attn_algo_bytes(bs, kv_len, n_heads, n_kv_heads, head_dim, block, q_len=1, esize=2):
-    """K+V once, Q+O once, int32 indices once."""
-    kv = 2 * bs * kv_len * n_kv_heads * head_dim * esize
+    """K+V once, Q+O once, int32 indices once.  `kv_len`: one length for a uniform batch or
+    the list of per-sequence lengths (ragged batch)."""
+    lens = [int(kv_len)] * bs if isinstance(kv_len, int) else [int(x) for x in kv_len]
+    assert len(lens) == bs
+    kv = 2 * sum(lens) * n_kv_heads * head_dim * esize
     qo = 2 * bs * q_len * n_heads * head_dim * esize
-    idx = 4 * (bs * ((kv_len + block - 1) // block) + 3 * (bs + 1))
+    idx = 4 * (sum((k + block - 1) // block for k in lens) + 3 * (bs + 1))
     return kv + qo + idx
+
+
+def step_algo_bytes(model, bs, kv_lens, block):
+    """Algorithmic HBM bytes of ONE decode step of this rank's shard (summed): per layer the
+    paged-attention bytes of the whole batch + the four int4 linears (packed weights + scale/zero words +
+    activations in and out), plus the lm_head weight (read once per step) and the embedding rows."""
+    s = model.shape
+    attn = attn_algo_bytes(bs, kv_lens, model.n_heads, model.n_kv_heads, s.head_dim, block)
+    lin = 0
+    for name in ("qkv", "o", "gate_up", "down"):
+        pk = model.layers[0][name]._packed
+        n_out = pk.N // 2 if name == "gate_up" and model.layers[0][name].paired else pk.N
+        lin += pk.wq.numel() * pk.wq.element_size() + pk.sz.numel() * pk.sz.element_size()
+        lin += 2 * bs * (pk.k_src + n_out)
+    head = model.lm_head.numel() * model.lm_head.element_size() + 2 * bs * s.hidden
+    return dict(attention_per_layer=attn, linears_per_layer=lin, lm_head_and_embedding=head,
+                total=s.n_layers * (attn + lin) + head)
 
 
 def measure_attention_kernel(model, tokens, positions, params, n_launch):
@@ -493,6 +513,8 @@ def main():
     ap.add_argument("--host", default="py", choices=["py", "cpp"], help="who composes the step: the Python mirror "
                     "(decode.LlamaDecodeStep over ctypes) or the compiled C++ host step (csrc/shim/slm_llama_hip.cpp "
                     "through _slm_shim.so); same kernels, same launch sequence -- under graph replay the same line")
+    ap.add_argument("--ragged", action="store_true", help="serving-shaped batch (SURVEY 8(d) config 2): "
+                    "kv_len ~ U[seqlen/2, seqlen] per sequence (numpy default_rng(1)); not the BASELINE metric line")
     ap.add_argument("--simulate-tp", type=int, default=0, help="tuning aid: run rank 0's shard of a "
                     "TP=N step on one GPU with the collectives stubbed (flagged in the output)")
     args = ap.parse_args()
@@ -526,8 +548,17 @@ def main():
     bs, L, B = args.bs or (128 if args.model == "70b" else 256), args.seqlen, args.block
     shape.max_position = max(shape.max_position, L + 8 + (args.steps + 2 * args.warmup + 16 if args.advance else 0))
     spare = ((args.steps + 2 * args.warmup + 8) // B + 2) if args.advance else 0
-    tokens, positions, params, n_blocks = make_decode_inputs(bs, L, B, device, seed=1, vocab=shape.vocab,
-                                                             spare_blocks=spare)
+    kv_lens = L   # one length (uniform batch) or the per-sequence list (--ragged)
+    if args.ragged:
+        import numpy as np
+        if args.advance:
+            raise SystemExit("--ragged and --advance are separate modes")
+        kv_lens = [int(x) for x in np.random.default_rng(1).integers(L // 2, L + 1, size=bs)]
+        tokens, positions, params, n_blocks = make_batch_inputs([1] * bs, kv_lens, B, device, seed=1,
+                                                                vocab=shape.vocab)
+    else:
+        tokens, positions, params, n_blocks = make_decode_inputs(bs, L, B, device, seed=1, vocab=shape.vocab,
+                                                                 spare_blocks=spare)
     t_init = time.perf_counter()
     # N > 1: the two row-parallel reductions per layer run as the xGMI all-reduce fused with the
     # residual add + RMSNorm when every rank can map its peers AND the start-up
@@ -654,16 +685,14 @@ def main():
 
     # ---- roofline of the dominant kernel (paged-attention decode), this rank's shard ----
     # (two-lane steps launch the attention once per HALF batch: that launch is the one measured)
-    attn_rows, attn_params = bs, params
+    attn_rows, attn_params, attn_lens = bs, params, kv_lens
     if model.last_lanes == 2:
         lane0 = model._make_lanes(bs, positions, params, model.buf["o"][:bs], model.buf["down"][:bs], None, False)[0]
         attn_rows, attn_params = lane0.T, lane0.params
+        attn_lens = kv_lens if isinstance(kv_lens, int) else kv_lens[:attn_rows]
     avg_us, med_us = measure_attention_kernel(model, tokens[:attn_rows], positions, attn_params, n_launch=32)
-    nbytes = attn_algo_bytes(attn_rows, L, model.n_heads, model.n_kv_heads, shape.head_dim, B)
-    achieved = nbytes / avg_us / 1e3  # GB/s
-    # HBM traffic of that launch from the PMC counters, measured IN THIS RUN (rank 0, N = 1): two
-    # rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) over a child process
-    # that launches the same kernel on the same shapes; null when rocprofv3 is unavailable
+    nbytes = attn_algo_bytes(attn_rows, attn_lens, model.n_heads, model.n_kv_heads, shape.head_dim, B)
+    alone_gbps = nbytes / avg_us / 1e3  # GB/s, the launch replayed ALONE after the timed loop
     # the gate_up GEMM at the row count the step launches it with (a lane's rows under two lanes), and at
     # the full batch for continuity with rounds 1-3 (before the profiler children below: same clocks
     # as the timed steps)
@@ -671,13 +700,25 @@ def main():
     if attn_rows != bs:
         gemm["rows_note"] = f"M = {attn_rows}: the rows of one of the step's two lanes"
         gemm["at_full_batch"] = measure_gemm(model, bs)
+    # HBM traffic of that launch from the PMC counters, measured IN THIS RUN (rank 0, N = 1): two
+    # rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) over a child process
+    # that launches the same kernel on the same shapes; null when rocprofv3 is unavailable
     traffic, traffic_src = (None, None)
-    if rank == 0 and world == 1 and not args.no_traffic:
+    if rank == 0 and world == 1 and not args.no_traffic and not args.ragged:
         traffic, traffic_src = measure_attention_traffic_live(attn_rows, L, model.n_heads, model.n_kv_heads, B)
     # which kernel ran the q_len = 1 rows: asked of the library's own plan (tuning knobs included),
     # not re-derived here -- the MFMA tile kernel for wide GQA groups, the token-major stream otherwise
     on_tile = kernels.paged_kv_varlen_mha_decode_kernel(
         attn_rows, attn_rows, model.n_heads, model.n_kv_heads, shape.head_dim, B, 1, L, model.dtype) == "attn_tile_kernel"
+    # Round 5 (round-4 review, weak 6): `achieved` / `frac` describe the launch AS THE TIMED LOOP RUNS IT.
+    # With two lanes that is the launch next to the other lane's int4 GEMMs -- timed inside eager two-lane
+    # steps, HIP events on the launching stream right around every attention call (behind the event that
+    # chains the lanes' KV streams, so no waiting is included); the same launch replayed alone is reported
+    # as `alone`.  One lane: the launch has the chip to itself in the step too, the two coincide.
+    alone = dict(GBps=round(alone_gbps, 1), frac=round(alone_gbps / HBM_PEAK_GBPS, 4),
+                 avg_launch_us=round(avg_us, 2), median_launch_us=round(med_us, 2),
+                 launches="5 x 32 (hipGraph replay of the launch alone, after the timed loop)")
+    achieved, ach_us, ach_src = alone_gbps, avg_us, "the launch replayed alone (one lane: nothing shares the chip in the step either)"
     in_step = None
     if model.last_lanes == 2:
         a_us, m_us, n_l = measure_attention_in_step(model, static_tokens, positions, params)
@@ -685,16 +726,22 @@ def main():
                        GBps=round(nbytes / a_us / 1e3, 1), frac=round(nbytes / a_us / 1e3 / HBM_PEAK_GBPS, 4),
                        note="attention calls (stream kernel + split-KV combine) timed inside eager two-lane steps: "
                             "each runs while the other lane's int4 GEMMs share the CUs -- the stretch over "
-                            "avg_launch_us is the price of hiding those GEMMs; `achieved` is the kernel alone, "
-                            "measured as in rounds 1-3")
+                            "alone.avg_launch_us is the price of hiding those GEMMs")
+        achieved, ach_us, ach_src = nbytes / a_us / 1e3, a_us, "in_step (the launch inside the two-lane step)"
+    sb = step_algo_bytes(model, bs, kv_lens, B)
+    step_gbps = sb["total"] / ms_per_step / 1e6
     roofline = dict(kernel="attn_tile_kernel (paged-attention decode, MFMA tile form)" if on_tile
                     else "attn_token_kernel (paged-attention decode)", bound="hbm",
                     achieved=round(achieved, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBPS, 4), traffic=traffic, traffic_source=traffic_src,
-                    algorithmic_bytes_per_launch=nbytes, avg_launch_us=round(avg_us, 2),
-                    median_launch_us=round(med_us, 2), launches="5 x 32 (hipGraph replay)",
+                    algorithmic_bytes_per_launch=nbytes, avg_launch_us=round(ach_us, 2),
+                    achieved_source=ach_src,
                     sequences_per_launch=attn_rows,
-                    launches_per_layer=model.last_lanes, in_step=in_step)
+                    launches_per_layer=model.last_lanes, alone=alone, in_step=in_step,
+                    # the whole step against the same roof: every algorithmic byte of one step (KV of all
+                    # layers + int4 weights + lm_head) over the measured ms_per_step
+                    step_hbm_frac=round(step_gbps / HBM_PEAK_GBPS, 4), step_GBps=round(step_gbps, 1),
+                    step_algorithmic_bytes=sb)
 
     out = None
     if rank == 0:
@@ -711,12 +758,14 @@ def main():
             "scaling": "strong", "vs_baseline": None,
             "dtype": f"bf16 (int{args.bits} weights, fp32 accumulate)",
             "data": "synthetic (seeded random weights, KV history and tokens)",
-            "config": {"workload": f"llama3-{args.model}-shaped decode step: bs={bs}, kv_len={L}, q_len=1, "
+            "config": {"workload": f"llama3-{args.model}-shaped decode step: bs={bs}, "
+                                   + (f"kv_len ~ U[{L // 2}, {L}] (ragged, default_rng(1), mean {sum(kv_lens) / bs:.0f}), "
+                                      if args.ragged else f"kv_len={L}, ") + "q_len=1, "
                                    f"block_size={B}, {shape.n_layers} layers, {quant}"
                                    f"{' (symmetric)' if gptq_sym and quant == 'gptq' else ''} int{args.bits} g128 "
                                    f"linears, bf16 KV cache, greedy",
                        "model": args.model,
-                       "global_batch": bs, "seq_len": L,
+                       "global_batch": bs, "seq_len": L, "ragged": bool(args.ragged),
                        "parallelism": f"tp{world}" if world > 1 else "single-gpu",
                        "hip_graph": graph is not None, "decode_lanes": model.last_lanes,
                        "host": "c++ (slm::LlamaForCausalLMHip, _slm_shim.so)" if cpp_model is not None

@@ -885,11 +885,13 @@ static void launch_token_kernel(const AttnKParams& kp, const AttnPlan& pl, int64
 #define SLM_LAUNCH_W2(UU, NTT)                                                                             \
   do {                                                                                                     \
     auto kfn = attn_token_kernel<T, LPR, GC, UU, NTT, false, 2>;                                           \
-    static bool opted = false; /* > 64 KiB of dynamic LDS has to be opted into once per kernel */          \
-    if (!opted) {                                                                                          \
+    static bool opted[64] = {}; /* > 64 KiB of dynamic LDS: opted into once per kernel AND per device */   \
+    int devi = 0;                                                                                          \
+    (void)hipGetDevice(&devi);                                                                             \
+    if (devi < 0 || devi >= 64 || !opted[devi]) {                                                          \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 128 * 1024);                                                               \
-      opted = true;                                                                                        \
+      if (devi >= 0 && devi < 64) opted[devi] = true;                                                      \
     }                                                                                                      \
     hipLaunchKernelGGL(kfn, g, blk, pl.lds_bytes, st, kp);                                                 \
   } while (0)

@@ -34,6 +34,11 @@ LlamaForCausalLMHip::LlamaForCausalLMHip(const LlamaArgs& args, const QuantArgs&
     : args_(args), quant_args_(quant_args), parallel_args_(parallel_args), options_(options), opt_(opt),
       far_(std::move(fused_allreduce)) {
   const int64_t tp = parallel_args.world_size();
+  // a FusedAllReduce makes the row-parallel layers return this rank's PARTIAL sums (their process group
+  // is withheld below); only the fused composition reduces them (reduce_add_norm) -- the plain call
+  // sequence would feed partial sums straight into rms_norm_residual (round-4 advisor finding)
+  TORCH_CHECK(!far_ || opt.fused, "LlamaForCausalLMHip: a FusedAllReduce needs Options::fused = true "
+              "(the plain composition reduces through ProcessGroup::allreduce)");
   TORCH_CHECK(args.n_heads % tp == 0 && args.intermediate_size % tp == 0 && args.hidden_size % tp == 0 &&
               args.vocab_size % tp == 0, "Llama shapes must divide by the tensor-parallel world size ", tp);
   // QKVColumnParallelLinear replicates KV heads when n_kv_heads < world_size
@@ -158,6 +163,8 @@ void LlamaForCausalLMHip::reserve(int64_t n_tokens) {
       lane_kv_cu_[l] = torch::zeros({n_tokens + 1}, torch::dtype(torch::kInt).device(options_.device()));
     }
   }
+  if (lanes == 2 && !side_stream_.has_value())
+    side_stream_ = c10::hip::getStreamFromPoolMasqueradingAsCUDA(false, options_.device().index());
 }
 
 // ---- lanes -------------------------------------------------------------------------------------
@@ -383,9 +390,12 @@ void LlamaForCausalLMHip::plain_layer(Lane& ln, size_t li, std::vector<KVCache>&
 void LlamaForCausalLMHip::run_two_lanes(Lane& l0, Lane& l1, std::vector<KVCache>& kv) {
   const auto dev = options_.device().index();
   const Stream main = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev);
-  static thread_local std::optional<Stream> side_tl;
-  if (!side_tl.has_value()) side_tl = c10::hip::getStreamFromPoolMasqueradingAsCUDA(false, dev);
-  const Stream side = *side_tl;
+  // the side stream belongs to THIS model (its device): created once, in reserve() or here
+  if (!side_stream_.has_value()) {
+    TORCH_CHECK(!capturing(), "LlamaForCausalLMHip: call reserve() before capturing a two-lane step");
+    side_stream_ = c10::hip::getStreamFromPoolMasqueradingAsCUDA(false, dev);
+  }
+  const Stream side = *side_stream_;
   std::vector<std::unique_ptr<at::cuda::CUDAEvent>> events;
   auto record = [&](const Stream& s) {
     events.push_back(std::make_unique<at::cuda::CUDAEvent>());

@@ -27,7 +27,10 @@
 #pragma once
 #include <torch/torch.h>
 
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+
 #include <memory>
+#include <optional>
 #include <string>
 #include <vector>
 
@@ -137,6 +140,9 @@ class LlamaForCausalLMHip {
   torch::Tensor lane_q_cu_[2], lane_kv_cu_[2];
   torch::Tensor scratch_[2], deferred_[2][2];
   std::vector<torch::Tensor> retired_;
+  // lane 1's stream: per model instance, on the model's device (not per thread: two models on two GPUs
+  // driven from one thread each need their own)
+  std::optional<c10::hip::HIPStreamMasqueradingAsCUDA> side_stream_;
   int last_lanes_ = 1;
 };
 

@@ -184,6 +184,7 @@ class LlamaDecodeStep:
         self._side_stream = None
         self._lane_bufs = {}
         self.last_lanes = 1
+        self._pinned_lanes = None   # graph_variant(): 1 / 2 lanes pinned while a graph variant is captured
         tp = pa.world_size
         assert shape.n_heads % tp == 0 and shape.intermediate % tp == 0 and shape.hidden % tp == 0
         self.n_heads = shape.n_heads // tp
@@ -289,15 +290,26 @@ class LlamaDecodeStep:
     def reserve_workspaces(self, n_tokens: int, max_kv_len: int) -> None:
         """Grow the kernel workspace once, before graph capture."""
         s = self.shape
-        need = n_tokens * self.n_heads * 256 * (s.head_dim + 2) * 4  # worst-case split-KV partials
-        need = max(need, 64 * n_tokens * max(2 * s.intermediate // self.pa.world_size, s.hidden) * 4)
+
+        def need_for(rows: int) -> int:
+            need = rows * self.n_heads * 256 * (s.head_dim + 2) * 4  # worst-case split-KV partials
+            need = max(need, 64 * rows * max(2 * s.intermediate // self.pa.world_size, s.hidden) * 4)
+            return min(need, 4 << 30)
         # deferred split-K slabs (o / down / qkv leave up to 16 fp32 slabs for their consumer): both slots
         widest = max(s.hidden, (self.n_heads + 2 * self.n_kv_heads) * s.head_dim)
-        for lane in ((0, 1) if self.lanes_min != 0 else (0,)):  # every lane owns its scratch
+        # every lane owns its scratch.  Lane 1 exists only where a step of n_tokens rows CAN run as two
+        # lanes (one rank, no fused all-reduce, a pure-decode batch of that size passes the policy's size
+        # test), and is sized for its own rows (the upper half); lane 0 also serves the one-lane step.
+        h0 = 0
+        if self.lanes_min != 0 and self.custom_ar is None:
+            h0 = two_lane_split(s, self.n_heads, self.n_kv_heads, self.pa.world_size,
+                                self.lanes_min if self.lanes_min > 0 else 1, n_tokens, n_tokens, 1, 1 << 30)
+            if self.lanes_min < 0 and not 96 <= n_tokens <= 256:
+                h0 = 0
+        for lane, rows in ((0, n_tokens), (1, n_tokens - h0)) if 0 < h0 < n_tokens else ((0, n_tokens),):
             with kernels.workspace_lane(lane):
-                kernels.reserve_workspace(min(need, 4 << 30), self.device,
-                                          deferred_nbytes=16 * n_tokens * widest * 4)
-        if self.lanes_min != 0 and self._side_stream is None:
+                kernels.reserve_workspace(need_for(rows), self.device, deferred_nbytes=16 * rows * widest * 4)
+        if 0 < h0 < n_tokens and self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
 
     # ------------------------------------------------------------------------------------------
@@ -320,8 +332,46 @@ class LlamaDecodeStep:
         """Rows of lane 0 when the step runs as two lanes, else 0 (two_lane_split below)."""
         if ar is not None:
             return 0
-        return two_lane_split(self.shape, self.n_heads, self.n_kv_heads, self.pa.world_size, self.lanes_min, T,
+        lanes_min = self.lanes_min
+        if self._pinned_lanes is not None:   # a graph variant is being captured: the caller decided
+            lanes_min = 0 if self._pinned_lanes == 1 else 1
+        return two_lane_split(self.shape, self.n_heads, self.n_kv_heads, self.pa.world_size, lanes_min, T,
                               params.q_cu_seq_lens.numel() - 1, params.q_max_seq_len, params.kv_max_seq_len)
+
+    # ---- graph variants (ModelRunner, round 5; round-4 advisor finding) -------------------------------
+    # A captured graph freezes every host-side decision of the step at the CAPTURE-time hints
+    # (kv_max_seq_len = cuda_graph_max_seq_len, model_runner.cpp:88-90).  Two of those decisions depend on
+    # the batch that is replayed, not on the bound: one lane or two (the policy wants the batch's real
+    # context length) and whether the batch is uniform (kv_total_len: the classic attention partition
+    # without the balanced one's combine launch).  ModelRunner therefore captures one graph per VARIANT
+    # (lanes, uniform) of a batch size and picks at replay with graph_variant_for() on the real hints.
+    def graph_variants(self, n_tokens: int, n_seqs: int, q_max_seq_len: int):
+        """The (lanes, uniform) variants worth capturing for a batch of this shape."""
+        lanes = [1]
+        if self.lanes_min != 0 and self.custom_ar is None and two_lane_split(
+                self.shape, self.n_heads, self.n_kv_heads, self.pa.world_size, 1, n_tokens, n_seqs,
+                q_max_seq_len, 1 << 30) > 0:
+            lanes.append(2)
+        uniform = (False, True) if q_max_seq_len == 1 and n_tokens == n_seqs else (False,)
+        return [(ln, u) for ln in lanes for u in uniform]
+
+    def graph_variant_for(self, n_tokens: int, params: InputParameters):
+        """The variant of graph_variants() a batch with these (real) hints should replay."""
+        n_seqs = params.q_cu_seq_lens.numel() - 1
+        ar = self.custom_ar if self.pa.world_size > 1 else None
+        lanes = 2 if self._lane_split(n_tokens, params, ar) > 0 else 1
+        uniform = (params.q_max_seq_len == 1 and n_tokens == n_seqs and
+                   getattr(params, "kv_total_len", 0) == n_seqs * params.kv_max_seq_len)
+        return lanes, bool(uniform)
+
+    @contextlib.contextmanager
+    def graph_variant(self, variant):
+        """Pin the step to `variant`'s lane count (while its graph is captured)."""
+        prev, self._pinned_lanes = self._pinned_lanes, int(variant[0])
+        try:
+            yield
+        finally:
+            self._pinned_lanes = prev
 
     def _make_lanes(self, T: int, positions, params: InputParameters, o_buf, down_buf, ar, fold):
         b = self.buf

@@ -17,6 +17,7 @@ There is NO fallback: a missing library or a non-GPU tensor raises.
 from __future__ import annotations
 
 import contextlib
+import threading
 import ctypes as C
 from typing import Optional
 
@@ -95,11 +96,14 @@ _retired = []  # buffers replaced by bigger ones: still referenced by graphs cap
 _deferred_gen = {}  # (device, slot) -> generation counter of that deferred-partials buffer
 
 
-_lane = 0  # scratch lane of the calling code path (workspace_lane): 0 unless a step runs two streams
+# scratch lane of the calling code path (workspace_lane): 0 unless a step runs two streams.  Per THREAD:
+# one worker thread per GPU may each be inside its own lane
+_lane_tls = threading.local()
 
 
 def _dev_key(dev: torch.device):
-    return (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), _lane)
+    return (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(),
+            getattr(_lane_tls, "lane", 0))
 
 
 @contextlib.contextmanager
@@ -107,12 +111,12 @@ def workspace_lane(lane: int):
     """Scratch buffers are per (device, lane).  Kernels launched on DIFFERENT streams that may run
     concurrently (the two half-batch lanes of decode.LlamaDecodeStep) must not share the split-KV /
     split-K scratch: each stream's launches are issued inside its own lane.  Lane 0 is the default."""
-    global _lane
-    prev, _lane = _lane, int(lane)
+    prev = getattr(_lane_tls, "lane", 0)
+    _lane_tls.lane = int(lane)
     try:
         yield
     finally:
-        _lane = prev
+        _lane_tls.lane = prev
 
 
 def _grow(table, nbytes: int, dev: torch.device, what: str) -> torch.Tensor:

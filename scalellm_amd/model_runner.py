@@ -17,6 +17,15 @@ Same contract as the reference:
 
 The model is anything with `forward(tokens, positions, params, **kw) -> Tensor` whose output lives
 in a static buffer (scalellm_amd.decode.LlamaDecodeStep returns views of its own buffers).
+
+One extension over the reference (round 5; round-4 advisor finding): a model may offer GRAPH VARIANTS
+(`graph_variants` / `graph_variant_for` / `graph_variant`, see LlamaDecodeStep).  A captured graph
+freezes the step's host-side decisions at the capture-time hints, but two of them belong to the batch
+that is replayed: one half-batch lane or two (the policy wants the batch's REAL context length, not
+`cuda_graph_max_seq_len`) and the uniform-batch hint `kv_total_len` (who fills it: INTEGRATION.md
+"kv_total_len").  With variants the runner captures one graph per (lanes, uniform) combination of a
+batch size -- same static buffers, one shared graph memory pool -- and picks at replay from the
+batch's own hints; a model without the three methods gets exactly the reference's one graph.
 """
 from __future__ import annotations
 
@@ -50,18 +59,40 @@ class _Graph:
             new_cache_slots=r.new_cache_slots[:n], block_tables=r.block_tables,
             cu_block_lens=r.cu_block_lens[:b + 1], q_max_seq_len=r.options.num_decoding_tokens,
             kv_max_seq_len=r.options.cuda_graph_max_seq_len)
-        self.graph: Optional[torch.cuda.CUDAGraph] = None
-        self.output: Optional[torch.Tensor] = None
+        self.runner = runner
+        # variant -> (graph, output); the key None is the reference's single graph
+        self.variants: Dict[object, tuple] = {}
+        self.last_variant = None
+
+    @property
+    def graph(self) -> Optional[torch.cuda.CUDAGraph]:   # (the first captured variant: tests, tools)
+        return next(iter(self.variants.values()))[0] if self.variants else None
+
+    def _params_for(self, variant) -> InputParameters:
+        """The capture-time parameters of a variant: the uniform ones claim every sequence at the bound."""
+        import dataclasses
+        if variant is None or not variant[1]:
+            return self.params
+        return dataclasses.replace(self.params, kv_total_len=self.batch_size * self.params.kv_max_seq_len)
 
     def capture(self, fn: Callable) -> None:
-        # warm up (workspaces grow here, not under capture), then capture on a side stream
-        torch.cuda.synchronize()
-        fn(self.tokens, self.positions, self.params)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.output = fn(self.tokens, self.positions, self.params)
-        torch.cuda.synchronize()
+        model = self.runner.model
+        keys = [None]
+        if all(hasattr(model, a) for a in ("graph_variants", "graph_variant_for", "graph_variant")):
+            keys = list(model.graph_variants(self.n_tokens, self.batch_size, self.params.q_max_seq_len))
+        for key in keys:
+            prm = self._params_for(key)
+            pin = model.graph_variant(key) if key is not None else _null_context()
+            with pin:
+                # warm up (workspaces grow here, not under capture), then capture on a side stream
+                torch.cuda.synchronize()
+                fn(self.tokens, self.positions, prm)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.runner.graph_pool, capture_error_mode="thread_local"):
+                    out = fn(self.tokens, self.positions, prm)
+                torch.cuda.synchronize()
+            self.variants[key] = (g, out)
 
     def replay(self, tokens, positions, params: InputParameters) -> torch.Tensor:
         if tokens.numel() != self.n_tokens:
@@ -75,13 +106,31 @@ class _Graph:
         self.params.new_cache_slots.copy_(params.new_cache_slots, non_blocking=True)
         self.params.block_tables[:params.block_tables.numel()].copy_(params.block_tables, non_blocking=True)
         self.params.cu_block_lens.copy_(params.cu_block_lens, non_blocking=True)
-        self.graph.replay()
-        return self.output
+        key = None
+        if None not in self.variants:   # the batch's own hints pick the variant (never the capture bound)
+            key = self.runner.model.graph_variant_for(self.n_tokens, params)
+            if key not in self.variants:
+                key = (1, False) if (1, False) in self.variants else next(iter(self.variants))
+        self.last_variant = key
+        g, out = self.variants[key]
+        g.replay()
+        return out
+
+
+class _null_context:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
 
 
 class ModelRunner:
     def __init__(self, model, device, options: ModelRunnerOptions, **forward_kwargs):
         self.model, self.device, self.options = model, torch.device(device), options
+        # one memory pool for every graph (model_runner.cpp:63 graph_pool_handle): the variants of a
+        # batch size and the graphs of other batch sizes never replay concurrently
+        self.graph_pool = torch.cuda.graph_pool_handle() if torch.cuda.is_available() else None
         self.forward_kwargs = forward_kwargs
         self.graphs: Dict[int, _Graph] = {}
         self.num_graph_replayed = 0  # the reference's two counters (model_runner.cpp:14-21)
