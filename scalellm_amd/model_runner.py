@@ -80,6 +80,7 @@ class _Graph:
         keys = [None]
         if all(hasattr(model, a) for a in ("graph_variants", "graph_variant_for", "graph_variant")):
             keys = list(model.graph_variants(self.n_tokens, self.batch_size, self.params.q_max_seq_len))
+        import gc
         for key in keys:
             prm = self._params_for(key)
             pin = model.graph_variant(key) if key is not None else _null_context()
@@ -89,8 +90,18 @@ class _Graph:
                 fn(self.tokens, self.positions, prm)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.runner.graph_pool, capture_error_mode="thread_local"):
-                    out = fn(self.tokens, self.positions, prm)
+                # no cyclic garbage collection while the stream is capturing: a collector run in the
+                # middle of a capture finalises HIP objects of EARLIER steps (events of the previous
+                # variant's two-lane step) on a capturing thread, which the runtime answers with an abort
+                gc.collect()
+                gc_was_on = gc.isenabled()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(g, pool=self.runner.graph_pool, capture_error_mode="thread_local"):
+                        out = fn(self.tokens, self.positions, prm)
+                finally:
+                    if gc_was_on:
+                        gc.enable()
                 torch.cuda.synchronize()
             self.variants[key] = (g, out)
 
