@@ -38,10 +38,12 @@ def cpp_params(params):
 
 
 def from_decode_step(step, block_size: int, max_tokens: int, fused: bool = True, lanes: int = -1,
-                     lanes_chain: bool = True):
+                     lanes_chain: bool = True, rank: int = 0, world_size: int = 1, kv_step=None):
     """slm::LlamaForCausalLMHip over the checkpoint tensors (LlamaDecodeStep(keep_checkpoint=True)), the
     KV cache tensors (shared, not copied) and the RoPE table of a Python step: the same model, hosted
-    in C++.  Single rank, 4-bit weights."""
+    in C++.  4-bit weights.  `step` is the single-rank step that holds the FULL checkpoint; with
+    world_size > 1 the C++ model keeps rank `rank`'s tensor-parallel shard of it (collectives stubbed:
+    slm::LocalShardProcessGroup) and shares the KV caches of `kv_step`, the Python step of that rank."""
     from .decode import hf_state_dict
     shim = load_shim()
     s = step.shape
@@ -53,10 +55,10 @@ def from_decode_step(step, block_size: int, max_tokens: int, fused: bool = True,
                                  max_position=s.max_position, rope_theta=s.rope_theta, rms_eps=s.rms_eps,
                                  quant_method=qa.quant_method, bits=4, group_size=qa.group_size, desc_act=False,
                                  max_tokens=max_tokens, fused=fused, decode_lanes=lanes, lanes_chain=lanes_chain,
-                                 device_index=step.device.index or 0)
+                                 device_index=step.device.index or 0, rank=rank, world_size=world_size)
     m.load_state_dict(hf_state_dict(step))
     m.verify_loaded_weights()
-    m.set_kv_caches([(L["kv"].key_cache, L["kv"].value_cache) for L in step.layers], block_size)
+    m.set_kv_caches([(L["kv"].key_cache, L["kv"].value_cache) for L in (kv_step or step).layers], block_size)
     m.set_cos_sin_cache(step.attn.handler.cos_sin)
     m.reserve(max_tokens)
     return m

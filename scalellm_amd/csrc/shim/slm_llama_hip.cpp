@@ -41,11 +41,17 @@ LlamaForCausalLMHip::LlamaForCausalLMHip(const LlamaArgs& args, const QuantArgs&
               "(the plain composition reduces through ProcessGroup::allreduce)");
   TORCH_CHECK(args.n_heads % tp == 0 && args.intermediate_size % tp == 0 && args.hidden_size % tp == 0 &&
               args.vocab_size % tp == 0, "Llama shapes must divide by the tensor-parallel world size ", tp);
-  // QKVColumnParallelLinear replicates KV heads when n_kv_heads < world_size
-  // (qkv_parallel_linear.cpp:28-38); this composition shards them evenly
-  TORCH_CHECK(args.n_kv_heads % tp == 0, "n_kv_heads ", args.n_kv_heads, " must divide by world_size ", tp);
+  // QKVColumnParallelLinearImpl (qkv_parallel_linear.cpp:22-38): KV heads are partitioned evenly when
+  // n_kv_heads >= world_size and REPLICATED (world_size / n_kv_heads ranks share a head) below that
+  if (args.n_kv_heads >= tp) {
+    TORCH_CHECK(args.n_kv_heads % tp == 0, "kv_heads can't be partitioned evenly across world_size");
+  } else {
+    TORCH_CHECK(tp % args.n_kv_heads == 0, "kv heads can't be replicated evenly across world_size");
+    kv_replication_ = tp / args.n_kv_heads;
+  }
+  const int64_t effective_kv_heads = kv_replication_ > 1 ? tp : args.n_kv_heads;
   n_heads_ = args.n_heads / tp;
-  n_kv_heads_ = args.n_kv_heads / tp;
+  n_kv_heads_ = effective_kv_heads / tp;
   const int64_t H = args.hidden_size, D = args.head_dim, I = args.intermediate_size;
   // AttentionHandler::create_handler_with_rope (handler.cpp:60-104): inv_freq = theta^(-2i/d)
   const auto idx = torch::arange(0, D, 2, torch::kFloat32);
@@ -56,7 +62,7 @@ LlamaForCausalLMHip::LlamaForCausalLMHip(const LlamaArgs& args, const QuantArgs&
   atten_ = std::make_unique<AttentionImpl>(n_heads_, n_kv_heads_, D, handler_.get());
   layers_.resize(args.n_layers);
   for (auto& L : layers_) {
-    L.qkv = std::make_shared<ColumnParallelQLinearHipImpl>(H, (args.n_heads + 2 * args.n_kv_heads) * D, false,
+    L.qkv = std::make_shared<ColumnParallelQLinearHipImpl>(H, (args.n_heads + 2 * effective_kv_heads) * D, false,
                                                            quant_args, /*gather_output=*/false, parallel_args,
                                                            options);
     // a caller-owned reduction (process_group == nullptr with world > 1): the FusedAllReduce path
@@ -91,7 +97,7 @@ void LlamaForCausalLMHip::load_state_dict(const StateDict& sd) {
     const auto lsd = sd.select("model.layers." + std::to_string(i) + ".");
     if (lsd.size() == 0) continue;
     auto& L = layers_[i];
-    L.qkv->load_state_dict(lsd.select("self_attn."), {"q_proj.", "k_proj.", "v_proj."});
+    L.qkv->load_state_dict(select_qkv(lsd), {"q_proj.", "k_proj.", "v_proj."});
     L.o->load_state_dict(lsd.select("self_attn.o_proj."));
     L.gate_up->load_state_dict(lsd.select("mlp."), {"gate_proj.", "up_proj."});
     L.down->load_state_dict(lsd.select("mlp.down_proj."));
@@ -100,6 +106,24 @@ void LlamaForCausalLMHip::load_state_dict(const StateDict& sd) {
     t = lsd.get_tensor("post_attention_layernorm.weight");
     if (t.defined()) L.post_norm = t.to(options_).contiguous();
   }
+}
+
+// The state_dict_selector of QKVColumnParallelLinearImpl (qkv_parallel_linear.cpp:44-69): with replicated
+// KV heads every k_proj / v_proj tensor is rewritten so that the even split over world_size hands rank r
+// head r / ratio -- the heads repeat-interleaved along the OUTPUT-feature dimension.  The reference
+// reshapes dim 0 (a dense [out, in] weight); the int4 checkpoint tensors carry the output features on
+// dim 1 (qweight [K, N/8] or [K/8, N], qzeros [G, N/8], scales [G, N]: a head is head_dim consecutive
+// columns = whole int32 words), a bias on dim 0.
+StateDict LlamaForCausalLMHip::select_qkv(const StateDict& layer_sd) const {
+  if (kv_replication_ <= 1) return layer_sd.select("self_attn.");
+  const int64_t n_kv = args_.n_kv_heads, ratio = kv_replication_;
+  return layer_sd.select_with_transform("self_attn.", [n_kv, ratio](const std::string& name, const torch::Tensor& t) {
+    if (name.rfind("k_proj.", 0) != 0 && name.rfind("v_proj.", 0) != 0) return t;
+    if (t.dim() == 1) return t.reshape({n_kv, -1}).repeat_interleave(ratio, 0).reshape({-1}).contiguous();
+    if (name.find("g_idx") != std::string::npos) return t;  // (rows, not output features)
+    const int64_t rows = t.size(0);
+    return t.reshape({rows, n_kv, -1}).repeat_interleave(ratio, 1).reshape({rows, -1}).contiguous();
+  });
 }
 
 void LlamaForCausalLMHip::verify_loaded_weights() const {

@@ -111,6 +111,7 @@ class LlamaForCausalLMHip {
     bool pend_residual = false;
     int qkv_splits = 0;
   };
+  StateDict select_qkv(const StateDict& layer_sd) const;
   int64_t lane_split(int64_t T, const InputParameters& p) const;
   std::vector<Lane> make_lanes(int64_t T, const torch::Tensor& positions, const InputParameters& p);
   void run_norm(Lane& ln);
@@ -130,6 +131,7 @@ class LlamaForCausalLMHip {
   Options opt_;
   std::shared_ptr<FusedAllReduce> far_;
   int64_t n_heads_ = 0, n_kv_heads_ = 0;
+  int64_t kv_replication_ = 0;  // world_size / n_kv_heads when KV heads are replicated, else 0
   std::unique_ptr<HipAttnHandler> handler_;
   std::unique_ptr<AttentionImpl> atten_;
   std::vector<Layer> layers_;

@@ -33,6 +33,16 @@ StateDict StateDict::select(const std::string& prefix) const {
   return StateDict(std::move(sel), prefix_ + prefix);
 }
 
+StateDict StateDict::select_with_transform(const std::string& prefix, TensorTransform transform_func) const {
+  std::unordered_map<std::string, torch::Tensor> sel;
+  for (const auto& kv : dict_)
+    if (kv.first.compare(0, prefix.size(), prefix) == 0) {
+      const std::string name = kv.first.substr(prefix.size());
+      sel[name] = transform_func ? transform_func(name, kv.second) : kv.second;
+    }
+  return StateDict(std::move(sel), prefix_ + prefix);
+}
+
 // ---------------------------------------------------------------------------------------------
 // common part
 // ---------------------------------------------------------------------------------------------

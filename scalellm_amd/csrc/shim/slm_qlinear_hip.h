@@ -23,6 +23,7 @@
 #pragma once
 #include <torch/torch.h>
 
+#include <functional>
 #include <memory>
 #include <string>
 #include <unordered_map>
@@ -78,6 +79,9 @@ class StateDict final {  // model_loader/state_dict.h:28-40 (the loading half is
                                    int world_size) const;
   // tensors whose name starts with prefix, renamed to the suffix
   StateDict select(const std::string& prefix) const;
+  // ... each passed through transform_func(suffix name, tensor) (state_dict.h:44-47)
+  using TensorTransform = std::function<torch::Tensor(const std::string&, const torch::Tensor&)>;
+  StateDict select_with_transform(const std::string& prefix, TensorTransform transform_func) const;
   size_t size() const { return dict_.size(); }
   const std::string& prefix() const { return prefix_; }
 

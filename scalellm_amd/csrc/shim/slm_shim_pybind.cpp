@@ -177,6 +177,7 @@ PYBIND11_MODULE(_slm_shim, m) {
   // Worker would own.  tests/test_shim_gpu.py holds it bit-identical to decode.LlamaDecodeStep;
   // bench.py --host cpp times it.
   struct PyLlama {
+    std::unique_ptr<slm::ProcessGroup> pg;  // world_size > 1: a LocalShardProcessGroup (one GPU, stubbed collectives)
     std::unique_ptr<slm::LlamaForCausalLMHip> model;
     std::vector<slm::KVCache> kv;
   };
@@ -185,7 +186,8 @@ PYBIND11_MODULE(_slm_shim, m) {
                                 int64_t intermediate, int64_t n_layers, int64_t vocab, int64_t max_position,
                                 double rope_theta, double rms_eps, const std::string& quant_method, int64_t bits,
                                 int64_t group_size, bool desc_act, int64_t max_tokens, bool fused,
-                                int64_t decode_lanes, bool lanes_chain, torch::ScalarType dtype, int device_index) {
+                                int64_t decode_lanes, bool lanes_chain, torch::ScalarType dtype, int device_index,
+                                int rank, int world_size) {
              slm::LlamaArgs a;
              a.hidden_size = hidden; a.n_heads = n_heads; a.n_kv_heads = n_kv_heads; a.head_dim = head_dim;
              a.intermediate_size = intermediate; a.n_layers = n_layers; a.vocab_size = vocab;
@@ -195,17 +197,22 @@ PYBIND11_MODULE(_slm_shim, m) {
              o.max_tokens = max_tokens; o.fused = fused; o.decode_lanes = decode_lanes; o.lanes_chain = lanes_chain;
              const bool awq = quant_method == "awq";
              auto p = std::make_unique<PyLlama>();
+             const torch::Device dev(torch::kCUDA, device_index);
+             // world_size > 1: rank `rank`'s shard of a TP model on this one GPU, collectives stubbed
+             if (world_size > 1) p->pg = std::make_unique<slm::LocalShardProcessGroup>(rank, world_size, dev);
              p->model = std::make_unique<slm::LlamaForCausalLMHip>(
                  a, make_args(quant_method, bits, group_size, desc_act, /*is_sym=*/false, /*zero_point=*/awq),
-                 slm::ParallelArgs(0, 1, nullptr), torch::dtype(dtype).device(torch::Device(torch::kCUDA, device_index)),
-                 o);
+                 slm::ParallelArgs(rank, world_size, p->pg.get()), torch::dtype(dtype).device(dev), o);
              return p;
            }),
            py::arg("hidden"), py::arg("n_heads"), py::arg("n_kv_heads"), py::arg("head_dim"), py::arg("intermediate"),
            py::arg("n_layers"), py::arg("vocab"), py::arg("max_position"), py::arg("rope_theta"), py::arg("rms_eps"),
            py::arg("quant_method"), py::arg("bits"), py::arg("group_size"), py::arg("desc_act"), py::arg("max_tokens"),
            py::arg("fused") = true, py::arg("decode_lanes") = -1, py::arg("lanes_chain") = true,
-           py::arg("dtype") = torch::kBFloat16, py::arg("device_index") = 0)
+           py::arg("dtype") = torch::kBFloat16, py::arg("device_index") = 0, py::arg("rank") = 0,
+           py::arg("world_size") = 1)
+      .def("n_local_heads", [](PyLlama& self) { return self.model->n_local_heads(); })
+      .def("n_local_kv_heads", [](PyLlama& self) { return self.model->n_local_kv_heads(); })
       .def("load_state_dict",
            [](PyLlama& self, std::unordered_map<std::string, torch::Tensor> sd) {
              self.model->load_state_dict(slm::StateDict(std::move(sd)));

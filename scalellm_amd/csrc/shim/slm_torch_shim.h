@@ -218,6 +218,27 @@ class ProcessGroupRCCL : public ProcessGroup {
   void* comm_;  // ncclComm_t
 };
 
+// Tuning / test aid (the C++ twin of model_parallel.LocalShardProcessGroup, bench.py --simulate-tp): behaves
+// like rank `rank` of a `world_size`-way group on ONE GPU with the collectives replaced by local stand-ins of
+// the same output shape (all-reduce = no-op, all-gather = world_size copies, all-to-all = copy).  The per-rank
+// COMPUTE and the weight sharding are exactly those of a real TP run; nothing measured or checked through
+// it is a multi-GPU result.
+class LocalShardProcessGroup : public ProcessGroup {
+ public:
+  LocalShardProcessGroup(int rank, int world_size, const torch::Device& device)
+      : ProcessGroup(rank, world_size, device) {}
+  void allreduce(torch::Tensor&) const override {}
+  void allgather(const torch::Tensor& input, std::vector<torch::Tensor>& outputs) const override {
+    for (auto& o : outputs) o.copy_(input);
+  }
+  void allgather(const torch::Tensor& input, torch::Tensor& outputs) const override {
+    outputs.view({world_size(), -1}).copy_(input.reshape({1, -1}).expand({world_size(), -1}));
+  }
+  void alltoall(const torch::Tensor& input, torch::Tensor& output) const override { output.copy_(input); }
+  void alltoall(const torch::Tensor& input, torch::Tensor& output, const std::vector<int64_t>&,
+                const std::vector<int64_t>&) const override { output.copy_(input); }
+};
+
 // The two row-parallel reductions of a decoder layer as ONE launch per rank each: two-shot
 // all-reduce over peer-mapped buffers fused with the residual add + RMSNorm that follows
 // (slm_allreduce, include/slm_hip.h section 6).  Replaces, at the call sites of

@@ -517,6 +517,7 @@ constexpr bool w4_pre_fits(int /*mt*/, int ntw, int ng, int pc) { return !(ntw =
 struct GemmPlan {
   int mt, ntw, ng, pc, post, small, gemv, split_k, chunks_per_split, n_mblocks, n_nblocks;
   int ks, ks_cw, ks_nw, ks_tpw, ks_mt;  // K-sliced small-M kernel (w4_ks.hip)
+  int m128, m128_wd;                    // 65 <= M <= 128 kernel (w4_m128.hip)
   size_t lds_bytes, part_bytes, aperm_bytes;
 };
 
@@ -719,6 +720,36 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
       pl->n_mblocks = 1;
       pl->n_nblocks = (n_tiles + tpw - 1) / tpw;
     }
+  }
+  // 65 <= M <= 128 (round 5): all rows in ONE workgroup (w4_m128.hip) -- every weight word fetched and
+  // dequantised once for 4 MFMAs instead of once per 64-row block for 2 -- in 132-VGPR / 32-KiB workgroups
+  // that sit twice on a CU next to the decode attention stream of the other lane.  Split-K aims at two
+  // workgroups per CU with >= 512 of K each (the consumers take up to 16 slabs).
+  pl->m128 = 0;
+  pl->m128_wd = 2;
+  if (tune_get(TUNE_W4_M128, 1) != 0 && a->M > 64 && a->M <= 128 && !pl->gemv && !pl->ks && !tune_is_set(TUNE_W4_MT) &&
+      a->K * a->N / 2 < ((int64_t)1 << 32) && (a->K / gs) * a->N * 4 < ((int64_t)1 << 32) &&
+      ((a->M - 1) * a->lda + a->K) * 2 < ((int64_t)1 << 31)) {
+    const int64_t tiles1 = (a->N + 127) / 128;
+    const int64_t target = tune_get(TUNE_W4_M128_SPLITS, 512);
+    int64_t want = (target + tiles1 / 2) / tiles1;
+    const int64_t cap = n_chunks / 4 > 0 ? n_chunks / 4 : 1;
+    if (want > cap) want = cap;
+    if (want > 16) want = 16;
+    if (want < 1) want = 1;
+    const int forced = tune_get(TUNE_W4_SPLITK, 0);
+    if (forced > 0) want = forced < n_chunks ? forced : n_chunks;
+    const int per = (int)((n_chunks + want - 1) / want);
+    pl->m128 = 1;
+    pl->mt = 4; pl->ntw = 1; pl->pc = 1; pl->post = 0;
+    pl->n_mblocks = 1;
+    pl->n_nblocks = (int)tiles1;
+    pl->chunks_per_split = per;
+    pl->split_k = (n_chunks + per - 1) / per;
+    int wd = tune_get(TUNE_W4_M128_WD, 2);
+    if (wd != 4 || (2 * per) % 4 != 0 || n_chunks % per != 0) wd = 2;
+    pl->m128_wd = wd;
+    pl->lds_bytes = W4_M128_LDS_BYTES;
   }
   pl->part_bytes = pl->split_k > 1 ? (size_t)pl->split_k * a->M * a->N * sizeof(float) : 0;
   pl->aperm_bytes = a->perm ? (((size_t)a->M * a->K * 2 + 255) & ~(size_t)255) : 0;
@@ -945,6 +976,8 @@ static int gemm_impl(const slm_w4_gemm_args* a, const slm_w4_norm_prologue* np, 
     launch_gemv(kp, a->dtype, pl.ng, st);
   else if (pl.small)
     launch_gemm_small(kp, a->dtype, pl.ng, pl.n_nblocks * pl.n_mblocks * pl.split_k, st);
+  else if (pl.m128)
+    launch_gemm_m128(kp, a->dtype, (int)a->group_size, pl.m128_wd, pl.n_nblocks * pl.split_k, st);
   else if (pl.mt == 16)
     launch_gemm_xl(kp, a->dtype, pl.ng, pl.n_nblocks * pl.n_mblocks * pl.split_k, st);
   else if (pl.mt == 8)

@@ -1,0 +1,256 @@
+// w4_m128.hip -- int4-weight x fp16/bf16-activation GEMM for 65 <= M <= 128 (round 5).
+//
+// Same operator as w4.hip (replaces marlin::gptq_gemm, reference gptq_gemm.cu:585-710; Marlin's
+// thread-block tile for this regime is gemm_kernel.cuh:49 with thread_m_blocks = 4), same packed
+// layout and scale/zero table (w4.hip header), same bit-faithful dequant (W4Dq<T>,
+// marlin/numeric_conversion.h:19-62).  This is the row count the two-lane decode step (decode.py,
+// DESIGN 3.6) runs ALL of its GEMMs at -- 128 rows per lane -- next to the other lane's attention
+// stream, and the row count of every 70B layer at bs = 128.
+//
+// What the general kernel does there, and why it is slow (round-4 review, weak 2): BM = 64 tiles --
+// every weight word is fetched and dequantised by TWO workgroups (one per 64-row block), 19 VALU per
+// word for 2 MFMAs; next to the attention stream (one wave per SIMD, ~65 % of the issue slots, high
+// priority) the GEMM is bound by its instruction count: 193 VALU per 16 MFMAs.  Its BM = 128 form
+// halves that but needs ~200 VGPRs and 64 KiB of LDS -- one workgroup per CU beside the attention
+// workgroup (200 VGPRs, 80 KiB) instead of two -- and measured slower in the step.
+//
+// This kernel: all 128 rows in one workgroup (MT = 4: a weight word is dequantised ONCE, 15 VALU with
+// the round-5 fp8-pair route, for 4 MFMAs = 3.75 VALU per MFMA), built to sit TWICE on a CU beside
+// the attention workgroup:
+//   * K chunks of 64 (one 16-B weight load per lane = exactly one kt block of the packed layout),
+//     double-buffered in 2 x 16 KiB of LDS (128 rows x 128 B, XOR-swizzled: slot ^ ((row >> 1) & 7)
+//     makes the 16-lane groups of ds_read_b128 hit 16 distinct bank quads);
+//   * <= 152 VGPRs (64 accumulators + a WD-deep weight ring + 16 staging registers), so two of its
+//     waves fit a SIMD next to a 200-VGPR attention wave (200 + 2 x 152 = 504 <= 512);
+//   * buffer resources for every address (32-bit offsets, no 64-bit VALU address math, branch-free
+//     predication of rows >= M), all VMEM visible to the compiler and issued in steady-state order:
+//     activations of chunk c + 1 first, then the weight / scale words of chunk c + WD, so the counted
+//     wait in front of the LDS stores leaves the whole weight ring in flight (VMEM returns in order).
+// Epilogues as in w4.hip: 16-bit store (+ bias), fp32 split-K slabs (reduce kernel or the consumer,
+// SLM_W4_DEFER_REDUCE), SiLU*mul on (gate, up) tile pairs held by adjacent waves (SLM_W4_SILU_MUL).
+#include "w4_common.h"
+
+namespace slm {
+
+constexpr int M128_KC = 64;               // K chunk of the main loop
+constexpr int M128_BUF = 128 * 128;       // one activation buffer: 128 rows x 64 k x 2 B
+constexpr uint32_t M128_OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t m128_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// NG: scale groups per 64-deep chunk (1: group size >= 64, 2: group size 32)
+// WD: weight ring depth in chunks (= unroll of the chunk loop; the host guarantees chunks % WD == 0)
+template <typename T, int NG, int WD>
+__global__ void __launch_bounds__(256, 3)
+w4a16_gemm_m128_kernel(const GemmKParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef typename Mfma<T>::frag frag_t;
+  constexpr int MT = 4;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb = (int)(blockIdx.x % (unsigned)p.n_nblocks);
+  const int ks = (int)(blockIdx.x / (unsigned)p.n_nblocks);
+  // split-K ranges are planned in 128-deep units (W4_KC); this loop walks 64-deep chunks
+  const int c0 = 2 * ks * p.chunks_per_split;
+  const int c1 = 2 * min(p.n_chunks, (ks + 1) * p.chunks_per_split);
+  const int nc = c1 - c0;
+  const int clast = 2 * p.n_chunks - 1;
+
+  const int n_tiles = (int)(p.N / 32);
+  const int gt = nb * 4 + wave;
+  const bool nvalid = gt < n_tiles;
+  const int ntile = nvalid ? gt : n_tiles - 1;  // (clamped: computes on the last valid tile, no store)
+
+  // ---- resources -------------------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t a_rs = m128_rsrc(p.a, (uint32_t)(((p.M - 1) * p.lda + p.K) * 2));
+  const __amdgpu_buffer_rsrc_t w_rs = m128_rsrc(p.wq, (uint32_t)((uint64_t)p.K * p.N / 2));
+  const __amdgpu_buffer_rsrc_t sz_rs = m128_rsrc(p.sz, (uint32_t)((uint64_t)p.ks_groups * p.N * 4));
+
+  // activations: thread -> 4 x (row, 16-B slot) of the 128 x 64 tile
+  uint32_t a_voff[4], a_lds[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    const int row = idx >> 3, slot = idx & 7;
+    const int rc = row < p.M ? row : (int)p.M - 1;  // rows >= M: clamped duplicates, never stored
+    a_voff[i] = (uint32_t)(2 * (rc * (int)p.lda + slot * 8));
+    a_lds[i] = (uint32_t)(row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+  }
+  const uint32_t w_voff = (uint32_t)ntile * 1024u + (uint32_t)lane * 16u;
+  const uint32_t kt_stride = (uint32_t)n_tiles * 1024u;  // bytes per 64-deep kt block row
+  const uint32_t sz_voff = (uint32_t)(ntile * 32 + (lane & 31)) * 4u;
+  const uint32_t sz_stride = (uint32_t)p.N * 4u;
+
+  u32x4 areg[4];
+  auto a_load = [&](int c) {  // chunk c (absolute, 64-deep) -> registers
+    const uint32_t soff = (uint32_t)min(c, clast) * 128u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      areg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)a_voff[i], (int)soff, 0));
+  };
+  auto a_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(smem + buf * M128_BUF + a_lds[i]) = areg[i];
+  };
+  // weights: plain (cacheable) loads -- the other lane of the decode step re-reads the layer within
+  // ~0.4 ms and finds it in the Infinity Cache (w4.hip, round 4)
+  auto w_load = [&](int c) -> u32x4 {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                         w_rs, (int)w_voff, (int)((uint32_t)min(c, clast) * kt_stride), 0));
+  };
+  auto sz_load = [&](int c, int g) -> uint32_t {
+    const uint32_t k = (uint32_t)min(c, clast) * 64u + (uint32_t)g * 32u;
+    const uint32_t grp = p.gs_shift >= 30 ? 0u : (k >> p.gs_shift);
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(sz_rs, (int)sz_voff, (int)(grp * sz_stride), 0);
+  };
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+  u32x4 wring[WD];
+  uint32_t szr[WD][NG];
+  frag_t bfrag[2];
+
+  auto dequant = [&](const u32x4 wv, const uint32_t (&sz)[NG], int j) -> frag_t {
+    const uint32_t word = j == 0 ? wv.x : j == 1 ? wv.y : j == 2 ? wv.z : wv.w;
+    const W4Dq<T> dq(sz[NG == 2 ? (j >> 1) : 0]);
+    uint32_t o[4];
+    dq.word(word, o);
+    const u32x4 packed = {o[0], o[1], o[2], o[3]};
+    return __builtin_bit_cast(frag_t, packed);
+  };
+
+  // ---- prologue: ring filled in steady-state order, chunk c0 staged ------------------------------
+  if (nc > 0) {
+    a_load(c0);
+#pragma unroll
+    for (int d = 0; d < WD; ++d) {
+      wring[d] = w_load(c0 + d);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) szr[d][g] = sz_load(c0 + d, g);
+    }
+    a_store(0);
+    bfrag[0] = dequant(wring[0], szr[0], 0);
+  }
+  __syncthreads();
+
+  const int mrow = lane & 31, kh = lane >> 5;
+  const uint32_t fr_base = (uint32_t)(mrow * 128);
+  const uint32_t fr_x = (uint32_t)((mrow >> 1) & 7);
+
+  for (int cb = 0; cb < nc; cb += WD) {
+#pragma unroll
+    for (int u = 0; u < WD; ++u) {
+      const int c = c0 + cb + u;        // this chunk; its weights sit in ring slot u
+      const int buf = u & 1;            // (WD is even: the buffer parity is static too)
+      a_load(c + 1);                    // (past the range: clamped reload, stored but never read)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cur = j & 1, nxt = cur ^ 1;
+        const int slot = 2 * j + kh;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const uint32_t off = (uint32_t)(buf * M128_BUF + m * 32 * 128) + fr_base +
+                               (((uint32_t)slot ^ fr_x) << 4);
+          const frag_t af = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(smem + off));
+          acc[m] = Mfma<T>::run(af, bfrag[cur], acc[m]);
+        }
+        // the next k-step's B fragment in the shadow of the MFMAs above
+        if (j < 3) {
+          bfrag[nxt] = dequant(wring[u], szr[u], j + 1);
+        } else {
+          const int un = (u + 1) % WD;
+          bfrag[nxt] = dequant(wring[un], szr[un], 0);
+        }
+        if (j == 3) {
+          // ring slot u is free (its last word was dequantised under k-step 2): re-issue it WD chunks
+          // ahead, AFTER this iteration's activation loads (older in the vmcnt queue)
+          __builtin_amdgcn_sched_barrier(0);
+          wring[u] = w_load(c + WD);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) szr[u][g] = sz_load(c + WD, g);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      a_store(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (p.silu && p.split_k == 1) {
+    // SLM_W4_SILU_MUL: column tiles are (gate, up) pairs held by waves (0, 1) and (2, 3): the up wave
+    // hands its T-rounded tile to the gate wave through the (now idle) activation buffers
+    const uint16_t* bias = reinterpret_cast<const uint16_t*>(p.bias);
+    uint16_t* ex = reinterpret_cast<uint16_t*>(smem) + (wave >> 1) * (MT * 1024);
+    if (wave & 1) {
+      const float bu = bias ? lo_f32<T>((uint32_t)bias[ntile * 32 + (lane & 31)]) : 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ex[(m * 16 + r) * 64 + lane] = pack1<T>(acc[m][r] + bu);
+    }
+    __syncthreads();
+    if ((wave & 1) || !nvalid) return;
+    const int64_t gcol = (int64_t)ntile * 32 + (lane & 31), ocol = (int64_t)(ntile >> 1) * 32 + (lane & 31);
+    const float bg = bias ? lo_f32<T>((uint32_t)bias[gcol]) : 0.f;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const float g = lo_f32<T>((uint32_t)pack1<T>(acc[m][r] + bg));
+        const float uu = lo_f32<T>((uint32_t)ex[(m * 16 + r) * 64 + lane]);
+        if (row < p.M) reinterpret_cast<uint16_t*>(p.c)[row * p.ldc + ocol] = pack1<T>(silu_mul1(g, uu));
+      }
+    }
+    return;
+  }
+  if (!nvalid) return;
+  const int64_t n = (int64_t)ntile * 32 + (lane & 31);
+  float bv = 0.f;
+  if (p.split_k == 1 && p.bias) bv = lo_f32<T>((uint32_t)reinterpret_cast<const uint16_t*>(p.bias)[n]);
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < p.M) {
+        if (p.split_k == 1)
+          reinterpret_cast<uint16_t*>(p.c)[row * p.ldc + n] = pack1<T>(acc[m][r] + bv);
+        else
+          p.part[((int64_t)ks * p.M + row) * p.N + n] = acc[m][r];
+      }
+    }
+  }
+}
+
+template <typename T>
+static void launch_m128_t(const GemmKParams& kp, int ng, int wd, int n_blocks, hipStream_t st) {
+  const dim3 grid((unsigned)n_blocks), blk(256);
+  const size_t lds = 2 * M128_BUF;
+#define SLM_M128(NGG, WDD) hipLaunchKernelGGL((w4a16_gemm_m128_kernel<T, NGG, WDD>), grid, blk, lds, st, kp)
+  if (ng == 2) {
+    if (wd == 4) SLM_M128(2, 4); else SLM_M128(2, 2);
+  } else {
+    if (wd == 4) SLM_M128(1, 4); else SLM_M128(1, 2);
+  }
+#undef SLM_M128
+}
+
+// group_size 32 -> two scale groups per 64-deep chunk; chunks (64-deep) per split must be a multiple of wd
+void launch_gemm_m128(const GemmKParams& kp, int dtype, int group_size, int wd, int n_blocks, hipStream_t st) {
+  const int ng = group_size == 32 ? 2 : 1;
+  if (dtype == SLM_BF16) launch_m128_t<bf16_tag>(kp, ng, wd, n_blocks, st);
+  else launch_m128_t<f16_tag>(kp, ng, wd, n_blocks, st);
+}
+
+}  // namespace slm

