@@ -38,9 +38,10 @@ enum TuneKey : int {
   TUNE_W4_KS_TPW,         // SLM_W4_KS_TPW         forced column tiles per workgroup
   TUNE_W4_KS_DBG,         // SLM_W4_KS_DBG         probe bits (1 = no activation loads, 2 = no weight loads): WRONG results
   TUNE_W4_KS_MT2,         // SLM_W4_KS_MT2         1 = 33 <= M <= 64 on the two-row-tile K-sliced stream (K <= 4096), 2 = any K; default 0
-  TUNE_W4_M128,           // SLM_W4_M128           0 = 65 <= M <= 128 stays on the general kernel (default 1: w4_m128.hip)
+  TUNE_W4_M128,           // SLM_W4_M128           w4_m128.hip at 65 <= M <= 128: 1 = always, 0 = never (default: K >= 8192)
   TUNE_W4_M128_WD,        // SLM_W4_M128_WD        weight ring depth of w4_m128.hip in 64-deep chunks (2 / 4)
   TUNE_W4_M128_SPLITS,    // SLM_W4_M128_SPLITS    workgroups w4_m128.hip's split-K aims at (default 512 = two per CU)
+  TUNE_W4_SPLIT_TARGET,   // SLM_W4_SPLIT_TARGET   workgroups the general kernel's split-K aims at for M > 64 (default 512)
   TUNE_COUNT
 };
 

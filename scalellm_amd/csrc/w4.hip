@@ -603,7 +603,7 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   const int n_units = n_chunks / pc;  // split-K granularity = whole passes
   int split_k = tune_get(TUNE_W4_SPLITK, 0);
   if (split_k <= 0) {
-    const int64_t target = (a->M <= 64 || mt >= 8) ? 256 : 512;
+    const int64_t target = (a->M <= 64 || mt >= 8) ? 256 : tune_get(TUNE_W4_SPLIT_TARGET, 512);
     int64_t want = (target + tiles / 2) / (tiles > 0 ? tiles : 1);
     // M > 64: keep >= 8 chunks (1024 of K) per split -- short K (row-parallel TP shards) does not
     // amortise the fp32 partial round trip
@@ -727,7 +727,15 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   // workgroups per CU with >= 512 of K each (the consumers take up to 16 slabs).
   pl->m128 = 0;
   pl->m128_wd = 2;
-  if (tune_get(TUNE_W4_M128, 1) != 0 && a->M > 64 && a->M <= 128 && !pl->gemv && !pl->ks && !tune_is_set(TUNE_W4_MT) &&
+  // Where (measured, profiles/r05_m128_*.jsonl): deep-K layers (K >= 8192: the Llama-3-70B shapes, where the
+  // general kernel already took its ~200-VGPR BM = 128 tiles) -- the 70B step 50.6 -> 49.4 ms.  On the
+  // Llama-3-8B shapes (K = 4096, and 14336 x 4096) it ties the BM = 64 general kernel alone and in the two-lane
+  // step: there the GEMMs are starved of HBM bandwidth by the attention stream, not bound by their
+  // instruction count (tools/probe_corun.py), and the plan with fewer, longer workgroups leaves the chain
+  // longer.  SLM_W4_M128 = 1 forces it everywhere (tests), 0 disables it.
+  const int m128_mode = tune_get(TUNE_W4_M128, -1);
+  if (m128_mode != 0 && (m128_mode > 0 || a->K >= 8192) && a->M > 64 && a->M <= 128 && !pl->gemv && !pl->ks &&
+      !tune_is_set(TUNE_W4_MT) &&
       a->K * a->N / 2 < ((int64_t)1 << 32) && (a->K / gs) * a->N * 4 < ((int64_t)1 << 32) &&
       ((a->M - 1) * a->lda + a->K) * 2 < ((int64_t)1 << 31)) {
     const int64_t tiles1 = (a->N + 127) / 128;
@@ -746,7 +754,9 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
     pl->n_nblocks = (int)tiles1;
     pl->chunks_per_split = per;
     pl->split_k = (n_chunks + per - 1) / per;
-    int wd = tune_get(TUNE_W4_M128_WD, 2);
+    // ring depth 4 where it was measured (Llama-3-70B shapes, profiles/r05_m128_70b_shapes.jsonl: layer 318 ->
+    // 310 us, gate_up 155 -> 148, down 83 -> 82); the general kernel's BM = 64 tiles: 336 us
+    int wd = tune_get(TUNE_W4_M128_WD, a->K >= 8192 ? 4 : 2);
     if (wd != 4 || (2 * per) % 4 != 0 || n_chunks % per != 0) wd = 2;
     pl->m128_wd = wd;
     pl->lds_bytes = W4_M128_LDS_BYTES;

@@ -194,7 +194,7 @@ def test_m128_kernel_grid(bits, wd, tune):
     split included), every group size (32 = two scale groups per chunk, -1 = per channel), both formats,
     act-order (column gather + padded groups), bias, fp32 split-K slabs, fp16 and bf16."""
     from scalellm_amd import kernels
-    tune(SLM_W4_M128_WD=wd)
+    tune(SLM_W4_M128=1, SLM_W4_M128_WD=wd)
     i = 0
     for M, N, K, gs, fmt, act, sk in (
             (65, 128, 128, 128, "awq", False, 0), (128, 256, 512, 128, "gptq", False, 0),
@@ -210,7 +210,7 @@ def test_m128_kernel_grid(bits, wd, tune):
         err = _rel_err(out, ref)
         assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, sk, err)
     # the kernel is what ran: the general kernel (SLM_W4_M128=0) agrees to summation order only
-    tune(SLM_W4_SPLITK=0)
+    tune(SLM_W4_SPLITK=0, SLM_W4_M128=1)
     case = helpers.make_quant_case(990, 1024, 512, 128, "awq", bits)
     a_out, ref = _run_gemm(case, bits, 128, bias=False, seed=3)
     tune(SLM_W4_M128=0)

@@ -69,11 +69,12 @@ PLANS = [
     (256, 1024, 1024, 128, dict(SLM_W4_MT=16, SLM_W4_SPLITK=1)),  # symmetric 256 x 256
     (384, 1024, 1280, 128, dict(SLM_W4_MT=16, SLM_W4_SPLITK=1)),
     (256, 4096, 2048, 128, dict()),                              # whatever the plan picks
-    (128, 2048, 1024, 128, dict()),                              # round 5: w4_m128.hip (65 <= M <= 128), the plan's split
-    (100, 1024, 512, 32, dict(SLM_W4_SPLITK=1)),                 # ... in-kernel pair exchange, two scale groups per chunk
-    (96, 4096, 1024, 64, dict(SLM_W4_SPLITK=4)),                 # ... fp32 slabs + the fused reduce
-    (128, 1024, 512, 128, dict(SLM_W4_M128_WD=4, SLM_W4_SPLITK=1)),  # ... four-chunk weight ring
-    (65, 1024, 448, 128, dict(SLM_W4_SPLITK=1)),                 # ... N = 7 tile pairs: a clamped wave pair
+    (128, 2048, 1024, 128, dict(SLM_W4_M128=1)),                 # round 5: w4_m128.hip (65 <= M <= 128), the plan's split
+    (100, 1024, 512, 32, dict(SLM_W4_M128=1, SLM_W4_SPLITK=1)),  # ... in-kernel pair exchange, two scale groups per chunk
+    (96, 4096, 1024, 64, dict(SLM_W4_M128=1, SLM_W4_SPLITK=4)),  # ... fp32 slabs + the fused reduce
+    (128, 1024, 512, 128, dict(SLM_W4_M128=1, SLM_W4_M128_WD=4, SLM_W4_SPLITK=1)),  # ... four-chunk weight ring
+    (65, 1024, 448, 128, dict(SLM_W4_M128=1, SLM_W4_SPLITK=1)),  # ... N = 7 tile pairs: a clamped wave pair
+    (128, 8192, 1024, 128, dict()),                              # ... K >= 8192: the plan's own choice
 ]
 
 
