@@ -572,6 +572,15 @@ def main():
         custom_ar = try_create_xgmi_allreduce(
             pg.rank, pg.world_size, bs, shape.hidden, torch.bfloat16, device,
             log=lambda m: print(f"[bench] {m}", file=sys.stderr))
+        # two lanes on a tensor-parallel rank (round 5): a second, independent instance of the protocol
+        # for lane 1 (its own signal block and message buffers).  Only when lanes are asked for: the
+        # automatic policy keeps TP shards on one lane (their per-rank KV stream is short).
+        if custom_ar is not None and args.lanes > 0:
+            ar1 = try_create_xgmi_allreduce(
+                pg.rank, pg.world_size, bs, shape.hidden, torch.bfloat16, device,
+                log=lambda m: print(f"[bench] lane 1: {m}", file=sys.stderr))
+            if ar1 is not None:
+                custom_ar = [custom_ar, ar1]
     model = LlamaDecodeStep(shape, bs, n_blocks, B, pa, quant_method=quant, group_size=128,
                             dtype=torch.bfloat16, device=device, seed=0, kv_fill=args.kv_fill,
                             custom_allreduce=custom_ar, gptq_sym=gptq_sym, bits=args.bits,
@@ -620,7 +629,8 @@ def main():
         would sit out its own 20 s timeout."""
         if custom_ar is None:
             return
-        err = torch.tensor([int(custom_ar.error())], dtype=torch.int32)
+        ars = custom_ar if isinstance(custom_ar, list) else [custom_ar]
+        err = torch.tensor([max(int(a.error()) for a in ars)], dtype=torch.int32)
         if torch.distributed.get_backend() == "nccl":
             err = err.to(device)
         torch.distributed.all_reduce(err, op=torch.distributed.ReduceOp.MAX)

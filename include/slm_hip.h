@@ -514,6 +514,44 @@ SLM_API int slm_allreduce(const slm_ar_args* args, void* stream);
  * algorithm be verified on a single GPU. */
 SLM_API int slm_allreduce_simulate(const slm_ar_args* ranks, int32_t world, void* stream);
 
+/* ========================================================================== */
+/* 7. Host policy: one lane or two for a pure-decode step (round 5)           */
+/*    no reference counterpart -- the two half-batch lanes are this build's   */
+/*    own schedule of the decoder stack (models/meta/llama.h:123-345 is one   */
+/*    serial chain per step); DESIGN.md 3.6.  Pure host code, no device work: */
+/*    ONE source of the rule for the Python mirror (decode.two_lane_split)    */
+/*    and the C++ host step (slm::LlamaForCausalLMHip::lane_split).           */
+/*    The rule: (a) hard conditions -- lanes_min != 0, a pure-decode batch in */
+/*    the reference's graph-replay sense (q_max_seq_len == 1 and n_tokens ==  */
+/*    n_seqs, model_runner.cpp:112-140), >= 64 tokens, one rank or a          */
+/*    tensor-parallel rank whose reductions may run on two streams            */
+/*    (tp_lanes_ok); (b) lanes_min > 0: every such batch of >= lanes_min      */
+/*    tokens; (c) lanes_min < 0 (auto): a MEASUREMENT recorded for this model */
+/*    geometry and batch size (slm_decode_lane_policy_record: the start-up    */
+/*    probe's one-lane vs two-lane time at a context length; the nearest      */
+/*    recorded length within a factor 1.5 decides), else the constants        */
+/*    measured on one MI355X for Llama-3-8B shapes (96 <= T <= 256, >= 12 MiB */
+/*    of K + V per sequence, KV bytes of the step >= 8 x the layer's weights).*/
+/* ========================================================================== */
+typedef struct slm_lane_query {
+  int32_t n_tokens, n_seqs, q_max_seq_len, kv_max_seq_len;
+  int32_t world_size;        /* tensor-parallel ranks                                        */
+  int32_t tp_lanes_ok;       /* world_size > 1: != 0 if the reductions may run on two streams */
+  int32_t lanes_min;         /* -1 auto, 0 never, N = every pure-decode batch of >= N tokens  */
+  int32_t n_heads, n_kv_heads, head_dim;   /* per rank                                        */
+  int64_t layer_weight_bytes;              /* packed weight bytes of one decoder layer, per rank */
+  int32_t kv_elem_bytes;     /* bytes per KV element (2)                                      */
+  int32_t reserved;
+} slm_lane_query;
+/* rows of lane 0 (a multiple of 32, about half the batch) when the step should run as two lanes, else 0 */
+SLM_API int32_t slm_decode_lane_split(const slm_lane_query* q);
+/* record a measurement for (geometry of q, n_tokens, kv_max_seq_len): time of the same layers as one lane
+ * and as two.  Process-wide table (<= 256 entries, oldest replaced); thread-safe. */
+SLM_API int slm_decode_lane_policy_record(const slm_lane_query* q, float one_lane_us, float two_lane_us);
+SLM_API int slm_decode_lane_policy_clear(void);
+/* 1 if a recorded measurement (not the constants) would decide q, else 0 */
+SLM_API int32_t slm_decode_lane_policy_measured(const slm_lane_query* q);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,15 @@ class W4NormPrologue(C.Structure):
     ]
 
 
+class LaneQuery(C.Structure):
+    """slm_lane_query (include/slm_hip.h section 7)."""
+    _fields_ = [("n_tokens", C.c_int32), ("n_seqs", C.c_int32), ("q_max_seq_len", C.c_int32),
+                ("kv_max_seq_len", C.c_int32), ("world_size", C.c_int32), ("tp_lanes_ok", C.c_int32),
+                ("lanes_min", C.c_int32), ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32),
+                ("head_dim", C.c_int32), ("layer_weight_bytes", C.c_int64), ("kv_elem_bytes", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class ArArgs(C.Structure):
     """struct slm_ar_args (include/slm_hip.h)."""
     _fields_ = [
@@ -177,6 +186,10 @@ def lib() -> C.CDLL:
         ("slm_ar_read_error", C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
         ("slm_allreduce", C.c_int, [C.POINTER(ArArgs), C.c_void_p]),
         ("slm_allreduce_simulate", C.c_int, [C.POINTER(ArArgs), C.c_int32, C.c_void_p]),
+        ("slm_decode_lane_split", C.c_int32, [C.POINTER(LaneQuery)]),
+        ("slm_decode_lane_policy_record", C.c_int, [C.POINTER(LaneQuery), C.c_float, C.c_float]),
+        ("slm_decode_lane_policy_clear", C.c_int, []),
+        ("slm_decode_lane_policy_measured", C.c_int32, [C.POINTER(LaneQuery)]),
     ]:
         fn = getattr(L, name)  # AttributeError here = library/header mismatch: fail loudly
         fn.restype = restype

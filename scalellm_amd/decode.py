@@ -110,46 +110,54 @@ def _shard_rows(ck, fmt, k0, k1, group_size, bits=4):
             "scales": ck["scales"][k0 // group_size:k1 // group_size].contiguous()}
 
 
+def lane_query(shape: "LlamaShape", n_heads: int, n_kv_heads: int, world_size: int, lanes_min: int,
+               n_tokens: int, n_seqs: int, q_max_seq_len: int, kv_max_seq_len: int, tp_lanes_ok: bool = False):
+    """slm_lane_query for a step of this shape (n_heads / n_kv_heads: per rank)."""
+    from ._lib import LaneQuery
+    q = LaneQuery()
+    q.n_tokens, q.n_seqs, q.q_max_seq_len, q.kv_max_seq_len = int(n_tokens), int(n_seqs), int(q_max_seq_len), \
+        int(min(kv_max_seq_len, 2 ** 31 - 1))
+    q.world_size, q.tp_lanes_ok, q.lanes_min = int(world_size), int(bool(tp_lanes_ok)), int(lanes_min)
+    q.n_heads, q.n_kv_heads, q.head_dim = int(n_heads), int(n_kv_heads), int(shape.head_dim)
+    # packed int4 bytes of one decoder layer on this rank: qkv + o + gate_up + down
+    q.layer_weight_bytes = (shape.hidden * (n_heads + 2 * n_kv_heads) * shape.head_dim +
+                            n_heads * shape.head_dim * shape.hidden +
+                            3 * shape.hidden * shape.intermediate // world_size) // 2
+    q.kv_elem_bytes = 2
+    return q
+
+
 def two_lane_split(shape: "LlamaShape", n_heads: int, n_kv_heads: int, world_size: int, lanes_min: int,
-                   n_tokens: int, n_seqs: int, q_max_seq_len: int, kv_max_seq_len: int) -> int:
-    """Rows of lane 0 when a step runs as two half-batch lanes (LlamaDecodeStep._run_two_lanes; the
-    same rule in csrc/shim/slm_llama_hip.cpp), else 0.  Pure host logic on the step's hints.
+                   n_tokens: int, n_seqs: int, q_max_seq_len: int, kv_max_seq_len: int,
+                   tp_lanes_ok: bool = False) -> int:
+    """Rows of lane 0 when a step runs as two half-batch lanes (LlamaDecodeStep._run_two_lanes), else 0.
+    Pure host logic on the step's hints; THE rule lives in the C ABI (slm_decode_lane_split,
+    include/slm_hip.h section 7, csrc/capi.hip) so that this mirror and the C++ host step
+    (csrc/shim/slm_llama_hip.cpp) cannot drift apart.
 
-    Two lanes need: one rank, a pure decode batch in the reference's graph-replay sense (every sequence
-    brings exactly one token: q_max_seq_len == 1 and n_tokens == n_seqs, the condition ModelRunner
-    replays on, model_runner.cpp:112-140, under which q_cu_seq_lens is the identity), and -- lanes_min:
-    -1 = auto, 0 = never, N = every such batch of >= N tokens (tests, sweeps; SLM_DECODE_LANES).
+    Two lanes need: one rank -- or a tensor-parallel rank whose row-parallel reductions can run on two
+    streams at once (tp_lanes_ok: one fused xGMI all-reduce instance PER LANE, round 5; a plain RCCL
+    communicator cannot) --, a pure decode batch in the reference's graph-replay sense (every sequence
+    brings exactly one token: q_max_seq_len == 1 and n_tokens == n_seqs, the condition ModelRunner replays
+    on, model_runner.cpp:112-140, under which q_cu_seq_lens is the identity), >= 64 tokens, and --
+    lanes_min: -1 = auto, 0 = never, N = every such batch of >= N tokens (tests, sweeps; SLM_DECODE_LANES).
 
-    auto: where two lanes were measured faster on one MI355X (Llama-3-8B shapes; profiles/r04_lanes_sweep.jsonl
-    and, with the stream kernel's two-chunk form, r04_lanes_sweep_w2.jsonl), all three of:
+    auto: a MEASUREMENT when one was recorded for this geometry and batch size (LlamaDecodeStep.probe_lanes:
+    the same layers timed as one lane and as two at a context length; the nearest recorded length within a
+    factor 1.5 decides); otherwise the constants measured on one MI355X for Llama-3-8B shapes
+    (profiles/r04_lanes_sweep.jsonl, r04_lanes_sweep_w2.jsonl), all three of:
       * 96 <= T <= 256.  At 4 k context, ms per step one lane -> two: T = 96 12.44 -> 11.91 (+4 %), 160 19.34 ->
         18.17 (+6 %), 192 21.55 -> 20.17 (+7 %), 224 24.92 -> 22.23 (+12 %), 256 26.10 -> 23.78 (+10 %); 64 the same;
         320 (-1 %) and 384 (-3 %) lose: halves beyond 128 rows put BOTH lanes' GEMMs past the M = 129 tile step.
-        (Before the two-chunk stream kernel freed issue slots for the co-running GEMMs, 192 and 224 lost.)
-      * long sequences: K + V bytes per sequence >= 12 MiB (3 k tokens of 8 KV heads x 128).  The halves' attention
-        launches have to be long against the fixed cost of a launch and against the GEMM chain they hide: at T = 256,
+      * long sequences: K + V bytes per sequence >= 12 MiB (3 k tokens of 8 KV heads x 128): at T = 256,
         context 4096 / 2048 / 1024 / 512: +10 / -4 / +2 / -5 %; T = 128: +4 / 0 / 0 / -6 %; T = 192 at 1024: -12 %.
       * the KV stream dominates the layer's weights (>= 8 x their bytes): Llama-3-70B shapes, T = 128 at 4096
         (5 x): -4...-7 %.
     """
-    T = n_tokens
-    if lanes_min == 0 or world_size != 1:
-        return 0
-    if q_max_seq_len != 1 or T != n_seqs or T < 64:
-        return 0
-    if lanes_min < 0:
-        if not 96 <= T <= 256:
-            return 0
-        if 4 * n_kv_heads * shape.head_dim * kv_max_seq_len < (12 << 20):
-            return 0
-        kv_bytes = 4 * n_kv_heads * shape.head_dim * T * kv_max_seq_len
-        w_bytes = (shape.hidden * (n_heads + 2 * n_kv_heads) * shape.head_dim +
-                   n_heads * shape.head_dim * shape.hidden + 3 * shape.hidden * shape.intermediate // world_size) // 2
-        if kv_bytes < 8 * w_bytes:
-            return 0
-    elif T < lanes_min:
-        return 0
-    return (T // 2 + 31) // 32 * 32
+    from . import _lib
+    q = lane_query(shape, n_heads, n_kv_heads, world_size, lanes_min, n_tokens, n_seqs, q_max_seq_len,
+                   kv_max_seq_len, tp_lanes_ok)
+    return int(_lib.lib().slm_decode_lane_split(q))
 
 
 class LlamaDecodeStep:
@@ -167,7 +175,14 @@ class LlamaDecodeStep:
         self.ckpt = [] if keep_checkpoint else None
         # optional custom_allreduce.XgmiAllReduce: the two row-parallel reductions of a layer then
         # run as ONE launch each, fused with the residual add + RMSNorm that follows
-        self.custom_ar = custom_allreduce
+        # Round 5: a PAIR (lane 0, lane 1) lets a tensor-parallel rank run two lanes: every lane owns a whole
+        # instance of the protocol (signal block + two alternating message buffers), so the lanes'
+        # reductions -- on two streams, in the same order on every rank -- never share a flag or a buffer
+        if isinstance(custom_allreduce, (list, tuple)):
+            self.custom_ars = [a for a in custom_allreduce if a is not None]
+        else:
+            self.custom_ars = [custom_allreduce] if custom_allreduce is not None else []
+        self.custom_ar = self.custom_ars[0] if self.custom_ars else None
         self.shape, self.pa, self.dtype, self.device = shape, pa, dtype, torch.device(device)
         self.defer_splitk = os.environ.get("SLM_DEFER_SPLITK", "1") != "0"  # read once, at build time
         # <= 4 tokens on one rank: the RMSNorm before the qkv / gate_up projections runs in the
@@ -301,9 +316,10 @@ class LlamaDecodeStep:
         # lanes (one rank, no fused all-reduce, a pure-decode batch of that size passes the policy's size
         # test), and is sized for its own rows (the upper half); lane 0 also serves the one-lane step.
         h0 = 0
-        if self.lanes_min != 0 and self.custom_ar is None:
+        if self.lanes_min != 0 and self._tp_lanes_ok():
             h0 = two_lane_split(s, self.n_heads, self.n_kv_heads, self.pa.world_size,
-                                self.lanes_min if self.lanes_min > 0 else 1, n_tokens, n_tokens, 1, 1 << 30)
+                                self.lanes_min if self.lanes_min > 0 else 1, n_tokens, n_tokens, 1, 1 << 30,
+                                tp_lanes_ok=True)
             if self.lanes_min < 0 and not 96 <= n_tokens <= 256:
                 h0 = 0
         for lane, rows in ((0, n_tokens), (1, n_tokens - h0)) if 0 < h0 < n_tokens else ((0, n_tokens),):
@@ -328,15 +344,24 @@ class LlamaDecodeStep:
         __slots__ = ("idx", "r0", "r1", "T", "positions", "params", "resid", "alt", "normed", "qkv",
                      "attn", "act", "gate_up", "o_buf", "down_buf", "pend", "fold", "stream", "q", "ar")
 
+    def _tp_lanes_ok(self) -> bool:
+        """May a tensor-parallel rank run its reductions on two streams at once?"""
+        if self.pa.world_size == 1:
+            return True
+        if self.custom_ar is not None:
+            return len(self.custom_ars) >= 2
+        return bool(getattr(self.pa.process_group, "lane_safe", False))   # (LocalShardProcessGroup: stubs)
+
     def _lane_split(self, T: int, params: InputParameters, ar) -> int:
         """Rows of lane 0 when the step runs as two lanes, else 0 (two_lane_split below)."""
-        if ar is not None:
+        if not self._tp_lanes_ok():
             return 0
         lanes_min = self.lanes_min
         if self._pinned_lanes is not None:   # a graph variant is being captured: the caller decided
             lanes_min = 0 if self._pinned_lanes == 1 else 1
         return two_lane_split(self.shape, self.n_heads, self.n_kv_heads, self.pa.world_size, lanes_min, T,
-                              params.q_cu_seq_lens.numel() - 1, params.q_max_seq_len, params.kv_max_seq_len)
+                              params.q_cu_seq_lens.numel() - 1, params.q_max_seq_len, params.kv_max_seq_len,
+                              tp_lanes_ok=True)
 
     # ---- graph variants (ModelRunner, round 5; round-4 advisor finding) -------------------------------
     # A captured graph freezes every host-side decision of the step at the CAPTURE-time hints
@@ -348,9 +373,9 @@ class LlamaDecodeStep:
     def graph_variants(self, n_tokens: int, n_seqs: int, q_max_seq_len: int):
         """The (lanes, uniform) variants worth capturing for a batch of this shape."""
         lanes = [1]
-        if self.lanes_min != 0 and self.custom_ar is None and two_lane_split(
+        if self.lanes_min != 0 and self._tp_lanes_ok() and two_lane_split(
                 self.shape, self.n_heads, self.n_kv_heads, self.pa.world_size, 1, n_tokens, n_seqs,
-                q_max_seq_len, 1 << 30) > 0:
+                q_max_seq_len, 1 << 30, tp_lanes_ok=True) > 0:
             lanes.append(2)
         uniform = (False, True) if q_max_seq_len == 1 and n_tokens == n_seqs else (False,)
         return [(ln, u) for ln in lanes for u in uniform]
@@ -403,8 +428,14 @@ class LlamaDecodeStep:
             ln.alt = b["resid_alt"][:T] if fold else None
             ln.qkv, ln.attn, ln.act = b["qkv"][r0:r1], b["attn"][r0:r1], b["act"][r0:r1]
             ln.gate_up = b["gate_up"][r0:r1] if b["gate_up"] is not None else None
-            ln.o_buf, ln.down_buf = o_buf[r0:r1], down_buf[r0:r1]
-            ln.fold, ln.stream, ln.ar = fold, None, ar
+            if ar is not None and len(ranges) == 2:
+                # the lane's own all-reduce instance: its partial sums go to rows [0, n) of ITS buffers
+                ln.ar = self.custom_ars[i]
+                ln.o_buf, ln.down_buf = ln.ar.buffer(0, r1 - r0), ln.ar.buffer(1, r1 - r0)
+            else:
+                ln.ar = ar
+                ln.o_buf, ln.down_buf = o_buf[r0:r1], down_buf[r0:r1]
+            ln.fold, ln.stream = fold, None
             lanes.append(ln)
         return lanes
 

@@ -92,6 +92,8 @@ class LocalShardProcessGroup(ProcessGroup):
     all-gather = N copies).  The per-rank COMPUTE is exactly that of a real TP=N run; numbers taken
     this way are flagged as simulated and never reported as multi-GPU results."""
 
+    lane_safe = True   # the stubs may run on two streams at once (decode.LlamaDecodeStep, lanes under TP)
+
     def __init__(self, world_size: int, rank: int = 0):
         self._group = None
         self._initialised = False

@@ -106,3 +106,30 @@ def test_bench_world_4_and_8_rehearsal_on_one_gpu(world, model):
     assert "xgmi" in fused["config"]["row_parallel_reduce"], (fused["config"], err_f[-1500:])
     tf, tp = fused["config"]["first_step_tokens"], plain["config"]["first_step_tokens"]
     assert len(tf) == 8 and tf == tp, f"fused vs collective reduce disagree at world {world}: {tf} vs {tp}"
+
+
+@pytest.mark.timeout(1800)
+def test_bench_two_ranks_with_two_lanes_each_on_one_gpu():
+    """Round 5: lanes under TP.  Two ranks on this GPU, each running its shard of a pure-decode batch of 128
+    rows as TWO half-batch lanes on two streams, every lane with its OWN instance of the fused all-reduce
+    (signal block + alternating message buffers over real interprocess mappings), captured into one
+    hipGraph per rank.  The fused reduce raises a sticky error word if a peer never arrives (bench.py
+    checks it after the warm-up and after the timed steps), so a protocol mix-up between the lanes'
+    instances fails loudly; the tokens must agree with the one-lane TP run up to near-ties (the lanes run
+    their GEMMs at half the rows: other split-K / tile plans)."""
+    big = ["--layers", "2", "--bs", "128", "--seqlen", "256", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-traffic", "--kv-fill", "consistent"]
+
+    def run(lanes):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2",
+               *big, "--lanes", str(lanes)]
+        return _run(cmd, dict(SLM_FORCE_LOCAL_RANK="0", SLM_DIST_BACKEND="gloo"))
+    two, err = run(64)
+    one, _ = run(0)
+    assert "xgmi" in two["config"]["row_parallel_reduce"], (two["config"], err[-1500:])
+    assert two["config"]["decode_lanes"] == 2 and one["config"]["decode_lanes"] == 1
+    assert two["config"]["hip_graph"] is True
+    t2, t1 = two["config"]["first_step_tokens"], one["config"]["first_step_tokens"]
+    agree = sum(int(a == b) for a, b in zip(t1, t2))
+    assert agree >= 12, f"two lanes per rank reproduce only {agree}/16 of the one-lane TP ids: {t1} vs {t2}"

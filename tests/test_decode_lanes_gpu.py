@@ -164,3 +164,45 @@ def test_model_runner_picks_the_graph_variant_from_the_replayed_batch():
         torch.cuda.synchronize()
         assert model.last_lanes == variant[0], name
         assert torch.equal(out, want), (name, float((out.float() - want.float()).abs().max()))
+
+
+def test_two_lanes_on_a_tensor_parallel_rank_equal_the_half_batches():
+    """Round 5: lanes under TP.  Rank 1 of a 2-way group on one GPU (collectives stubbed,
+    LocalShardProcessGroup -- lane-safe by construction): the sharded step as two lanes gives, row range
+    by row range, exactly what the sharded one-lane step over that half alone gives."""
+    from scalellm_amd.decode import LlamaDecodeStep, LlamaShape
+    from scalellm_amd.model_parallel import LocalShardProcessGroup, ParallelArgs
+    bs, B, n_blocks = 96, 16, 96 * 32 + 8
+    shape = LlamaShape(hidden=512, n_heads=16, n_kv_heads=2, head_dim=32, intermediate=512, n_layers=2,
+                       vocab=1024, max_position=512)
+    pa = ParallelArgs(rank=1, world_size=2, process_group=LocalShardProcessGroup(2, rank=1))
+    model = LlamaDecodeStep(shape, bs, n_blocks, B, pa, quant_method="awq", group_size=128, dtype=torch.bfloat16,
+                            device=DEV, seed=8)
+    g = torch.Generator(device=DEV).manual_seed(108)
+    for L in model.layers:
+        L["kv"].key_cache.normal_(generator=g)
+        L["kv"].value_cache.normal_(generator=g)
+    snap = [(L["kv"].key_cache.clone(), L["kv"].value_cache.clone()) for L in model.layers]
+
+    def restore():
+        for L, (k0, v0) in zip(model.layers, snap):
+            L["kv"].key_cache.copy_(k0)
+            L["kv"].value_cache.copy_(v0)
+
+    rng = np.random.default_rng(2)
+    kv = [int(x) for x in rng.integers(1, 450, size=bs)]
+    tokens, positions, params = _batch(rng, bs, 1, kv, B, n_blocks, shape.vocab)
+    model.lanes_min = 64
+    model.reserve_workspaces(bs, 496)
+    got = model.forward(tokens, positions, params, return_logits=True).clone()
+    torch.cuda.synchronize()
+    assert model.last_lanes == 2
+    h = model._lane_split(bs, params, None)
+    restore()
+    model.lanes_min = 0
+    for r0, r1 in ((0, h), (h, bs)):
+        half = model.forward(tokens[r0:r1], positions[r0:r1], _slice_params(params, r0, r1), return_logits=True)
+        torch.cuda.synchronize()
+        assert model.last_lanes == 1
+        assert torch.equal(got[r0:r1], half), (r0, r1, float((got[r0:r1].float() - half.float()).abs().max()))
+        restore()
