@@ -124,10 +124,14 @@ def measure_attention_in_step(model, tokens, positions, params, n_steps=2):
     events = []
     orig = model._attn
 
-    def timed(ln, li):
+    def timed(ln, li, phase=0):
+        if phase == 2:            # (the combine pass: issued right behind phase 1; one call = both)
+            orig(ln, li, phase)
+            events[-1][1].record()
+            return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        orig(ln, li)
+        orig(ln, li, phase)
         e1.record()
         events.append((e0, e1))
     model._attn = timed
@@ -588,6 +592,12 @@ def main():
     if args.lanes >= 0:
         model.lanes_min = args.lanes
     model.reserve_workspaces(bs, L)
+    # start-up probe of the lane policy (round 5): with lanes on "auto" the step's shape is timed as one lane
+    # and as two on a few layers, and the measurement -- not the Llama-3-8B constants -- decides
+    lane_probe = None
+    if model.lanes_min < 0 and not args.advance and os.environ.get("SLM_LANE_PROBE", "1") != "0":
+        if model.probe_lanes(bs, L) is not None:
+            lane_probe = model.last_probe
     cpp_model = cpp_prm = None
     if args.host == "cpp":
         if world != 1 or args.simulate_tp > 1 or args.bits != 4:
@@ -778,6 +788,9 @@ def main():
                        "global_batch": bs, "seq_len": L, "ragged": bool(args.ragged),
                        "parallelism": f"tp{world}" if world > 1 else "single-gpu",
                        "hip_graph": graph is not None, "decode_lanes": model.last_lanes,
+                       "lane_policy": (dict(lane_probe, source="start-up probe (LlamaDecodeStep.probe_lanes)")
+                                       if lane_probe else
+                                       {"source": "forced" if model.lanes_min >= 0 else "constants (no probe ran)"}),
                        "host": "c++ (slm::LlamaForCausalLMHip, _slm_shim.so)" if cpp_model is not None
                                else "python mirror (decode.LlamaDecodeStep over ctypes)", "reduced_model": reduced,
                        "row_parallel_reduce": (None if world == 1 else

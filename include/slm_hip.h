@@ -121,6 +121,12 @@ typedef struct slm_attn_args {
                              * the balanced partition and with it the combine launch that would find
                              * nothing to merge.  Like max_kv_len it only shapes the launch: results are
                              * correct whatever the value (a wrong "uniform" claim costs balance, not bits) */
+  int32_t phase;            /* 0 = the whole call (default).  A call that splits the KV range runs as stream
+                             * kernel(s) + a combine pass; a host that overlaps calls on two streams (the two
+                             * decode lanes) may issue the halves separately: 1 = everything BUT
+                             * the combine pass, 2 = the combine pass only (a no-op when the plan needs none).
+                             * Same arguments for both; phase 1 then phase 2 on one stream == phase 0. */
+  int32_t reserved;
 } slm_attn_args;
 
 /* Scratch needed for `a` (depends only on host-side sizes; AttentionHandler::

@@ -37,6 +37,7 @@ class AttnArgs(C.Structure):
         ("sm_scale", C.c_float), ("logits_soft_cap", C.c_float), ("sliding_window", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("num_splits", C.c_int32), ("total_kv_len", C.c_int32),
+        ("phase", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -978,6 +978,8 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
     if (a->o_stride[i] % 8 || a->q_stride[i] % 8 || a->k_stride[i] % 8 || a->v_stride[i] % 8)
       return SLM_ERR_ALIGNMENT;
 
+  if (a->phase < 0 || a->phase > 2) return SLM_ERR_INVALID_ARG;
+  const bool do_stream = a->phase != 2, do_combine = a->phase != 1;
   AttnKParams kp;
   kp.out = a->out; kp.q = a->query; kp.kc = a->key_cache; kp.vc = a->value_cache;
   kp.o_ts = a->o_stride[0]; kp.o_hs = a->o_stride[1];
@@ -1039,13 +1041,13 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
     const int64_t max_rows = (int64_t)a->max_q_len * kp.group;
     AttnKParams tk = kp;
     token_rows_possible = !(uniform_q && max_rows >= first_tile_rows);
-    if (first_tile_rows < 33 && !(uniform_q && max_rows > 32)) {  // (group >= 32: every multi-row sequence already has > 32 rows)
+    if (do_stream && first_tile_rows < 33 && !(uniform_q && max_rows > 32)) {  // (group >= 32: every multi-row sequence already has > 32 rows)
       tk.rows_lo = first_tile_rows;
       tk.rows_hi = 33;
       rc = launch_attn_tile(tk, a->dtype, max_rows < 32 ? max_rows : 32, st);
       if (rc != SLM_OK) return rc;
     }
-    if (max_rows > 32) {
+    if (do_stream && max_rows > 32) {
       // rows <= group (q_len = 1) stay with the token-major kernel also when group > 32 (MQA)
       tk.rows_lo = first_tile_rows > 33 ? first_tile_rows : 33;
       tk.rows_hi = 0x7fffffff;
@@ -1059,7 +1061,7 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
   hip_clear_error();
   const int64_t grid = (int64_t)a->n_tokens * pl.nhgb * pl.n_chunks * pl.n_splits;
   if (grid <= 0 || grid > 0x7fffffffLL) return SLM_ERR_INVALID_ARG;
-  if (!(tile_used && (dec_tile || !token_rows_possible))) {  // (every sequence has >= group rows: nothing left for it then)
+  if (do_stream && !(tile_used && (dec_tile || !token_rows_possible))) {  // (every sequence has >= group rows: nothing left for it then)
     if (a->dtype == SLM_BF16)
       dispatch_lpr<bf16_tag>(kp, pl, grid, st);
     else
@@ -1067,7 +1069,7 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
     rc = hip_check_launch();
     if (rc != SLM_OK) return rc;
   }
-  if (pl.n_splits > 1 || pl.bal) {
+  if (do_combine && (pl.n_splits > 1 || pl.bal)) {
     const int64_t items = (int64_t)a->n_tokens * a->n_heads;
     const dim3 g((unsigned)((items + 3) / 4)), blk(256);
     int lps_shift = 3;  // lanes per split: power of two >= head_dim / 4

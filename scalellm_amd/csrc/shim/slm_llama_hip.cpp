@@ -30,9 +30,10 @@ bool capturing() { return c10::hip::currentStreamCaptureStatusMayInitCtx() != c1
 
 LlamaForCausalLMHip::LlamaForCausalLMHip(const LlamaArgs& args, const QuantArgs& quant_args,
                                          const ParallelArgs& parallel_args, const torch::TensorOptions& options,
-                                         const Options& opt, std::shared_ptr<FusedAllReduce> fused_allreduce)
+                                         const Options& opt, std::shared_ptr<FusedAllReduce> fused_allreduce,
+                                         std::shared_ptr<FusedAllReduce> fused_allreduce_lane1)
     : args_(args), quant_args_(quant_args), parallel_args_(parallel_args), options_(options), opt_(opt),
-      far_(std::move(fused_allreduce)) {
+      far_(std::move(fused_allreduce)), far_lane1_(std::move(fused_allreduce_lane1)) {
   const int64_t tp = parallel_args.world_size();
   // a FusedAllReduce makes the row-parallel layers return this rank's PARTIAL sums (their process group
   // is withheld below); only the fused composition reduces them (reduce_add_norm) -- the plain call
@@ -175,7 +176,7 @@ void LlamaForCausalLMHip::reserve(int64_t n_tokens) {
   size_t need = static_cast<size_t>(n_tokens) * n_heads_ * 256 * (args_.head_dim + 2) * 4;  // split-KV partials
   need = std::max(need, static_cast<size_t>(64) * n_tokens * widest * 4);                   // split-K partials
   need = std::min<size_t>(need, static_cast<size_t>(4) << 30);
-  const int lanes = opt_.decode_lanes != 0 && opt_.fused ? 2 : 1;
+  const int lanes = opt_.decode_lanes != 0 && opt_.fused && tp_lanes_ok() ? 2 : 1;  // (lane 1 only where it can run)
   for (int l = 0; l < lanes; ++l) {
     scratch(l, need);
     for (int s = 0; s < 2; ++s) deferred(l, s, static_cast<size_t>(16) * n_tokens * widest * 4);
@@ -192,26 +193,35 @@ void LlamaForCausalLMHip::reserve(int64_t n_tokens) {
 }
 
 // ---- lanes -------------------------------------------------------------------------------------
+bool LlamaForCausalLMHip::tp_lanes_ok() const {
+  // may this rank's row-parallel reductions run on two streams at once?  One rank: nothing to reduce; a
+  // fused all-reduce instance PER LANE (round 5); the one-GPU stand-in group.  A plain RCCL communicator: no.
+  if (parallel_args_.world_size() == 1) return true;
+  if (far_) return far_lane1_ != nullptr;
+  return dynamic_cast<const LocalShardProcessGroup*>(parallel_args_.process_group()) != nullptr;
+}
+
 int64_t LlamaForCausalLMHip::lane_split(int64_t T, const InputParameters& p) const {
-  // same policy as decode.LlamaDecodeStep._lane_split (measured there: profiles/r04_lanes_sweep.jsonl)
-  const int64_t n_seqs = p.q_cu_seq_lens.size(0) - 1;
-  if (!opt_.fused || opt_.decode_lanes == 0 || parallel_args_.world_size() != 1) return 0;
-  if (p.q_max_seq_len != 1 || T != n_seqs || T < 64) return 0;
-  if (opt_.decode_lanes < 0) {
-    if (!(96 <= T && T <= 256)) return 0;
-    // ... long sequences (>= 12 MiB of K + V each) ...
-    if (4 * n_kv_heads_ * args_.head_dim * static_cast<int64_t>(p.kv_max_seq_len) < (int64_t(12) << 20)) return 0;
-    // ... and only while the KV stream dominates the layer (>= 8 x the layer's weight bytes)
-    const int64_t kv_bytes = 4 * n_kv_heads_ * args_.head_dim * T * static_cast<int64_t>(p.kv_max_seq_len);
-    const int64_t tp = parallel_args_.world_size();
-    const int64_t w_bytes = (args_.hidden_size * (n_heads_ + 2 * n_kv_heads_) * args_.head_dim +
-                             n_heads_ * args_.head_dim * args_.hidden_size +
-                             3 * args_.hidden_size * args_.intermediate_size / tp) / 2;
-    if (kv_bytes < 8 * w_bytes) return 0;
-  } else if (T < opt_.decode_lanes) {
-    return 0;
-  }
-  return (T / 2 + 31) / 32 * 32;
+  // THE rule is slm_decode_lane_split (include/slm_hip.h section 7): one source for this class and the Python
+  // mirror (decode.two_lane_split), measured overrides included
+  if (!opt_.fused) return 0;
+  const int64_t tp = parallel_args_.world_size();
+  slm_lane_query q{};
+  q.n_tokens = static_cast<int32_t>(T);
+  q.n_seqs = static_cast<int32_t>(p.q_cu_seq_lens.size(0) - 1);
+  q.q_max_seq_len = p.q_max_seq_len;
+  q.kv_max_seq_len = p.kv_max_seq_len;
+  q.world_size = static_cast<int32_t>(tp);
+  q.tp_lanes_ok = tp_lanes_ok() ? 1 : 0;
+  q.lanes_min = static_cast<int32_t>(opt_.decode_lanes);
+  q.n_heads = static_cast<int32_t>(n_heads_);
+  q.n_kv_heads = static_cast<int32_t>(n_kv_heads_);
+  q.head_dim = static_cast<int32_t>(args_.head_dim);
+  q.layer_weight_bytes = (args_.hidden_size * (n_heads_ + 2 * n_kv_heads_) * args_.head_dim +
+                          n_heads_ * args_.head_dim * args_.hidden_size +
+                          3 * args_.hidden_size * args_.intermediate_size / tp) / 2;
+  q.kv_elem_bytes = 2;
+  return slm_decode_lane_split(&q);
 }
 
 std::vector<LlamaForCausalLMHip::Lane> LlamaForCausalLMHip::make_lanes(int64_t T, const torch::Tensor& positions,
@@ -223,6 +233,7 @@ std::vector<LlamaForCausalLMHip::Lane> LlamaForCausalLMHip::make_lanes(int64_t T
   else ranges = {{0, h0}, {h0, T}};
   auto o_all = far_ ? far_->buffer(0, T) : o_.narrow(0, 0, T);
   auto down_all = far_ ? far_->buffer(1, T) : down_.narrow(0, 0, T);
+  FusedAllReduce* fars[2] = {far_.get(), far_lane1_.get()};
   std::vector<Lane> lanes;
   for (size_t i = 0; i < ranges.size(); ++i) {
     const auto [r0, r1] = ranges[i];
@@ -251,7 +262,14 @@ std::vector<LlamaForCausalLMHip::Lane> LlamaForCausalLMHip::make_lanes(int64_t T
     ln.resid = resid_.narrow(0, r0, n); ln.normed = normed_.narrow(0, r0, n);
     ln.qkv = qkv_.narrow(0, r0, n); ln.attn = attn_.narrow(0, r0, n);
     ln.act = act_.narrow(0, r0, n); ln.gate_up = gate_up_.narrow(0, r0, n);
-    ln.o_buf = o_all.narrow(0, r0, n); ln.down_buf = down_all.narrow(0, r0, n);
+    if (far_ && ranges.size() == 2) {
+      // the lane's own all-reduce instance: its partial sums go to rows [0, n) of ITS message buffers
+      ln.far = fars[i];
+      ln.o_buf = ln.far->buffer(0, n); ln.down_buf = ln.far->buffer(1, n);
+    } else {
+      ln.far = far_.get();
+      ln.o_buf = o_all.narrow(0, r0, n); ln.down_buf = down_all.narrow(0, r0, n);
+    }
     lanes.push_back(std::move(ln));
   }
   return lanes;
@@ -279,8 +297,8 @@ void LlamaForCausalLMHip::run_norm(Lane& ln) {
 void LlamaForCausalLMHip::reduce_add_norm(Lane& ln, int which, torch::Tensor& partial,
                                           const torch::Tensor& weight, int splits, int slot) {
   const int64_t n = ln.r1 - ln.r0;
-  if (far_) {  // ONE launch: two-shot all-reduce + residual add + RMSNorm (slm_allreduce)
-    far_->allreduce_residual_rmsnorm(which, n, ln.normed, ln.resid, weight, args_.rms_norm_eps);
+  if (ln.far != nullptr) {  // ONE launch: two-shot all-reduce + residual add + RMSNorm (slm_allreduce)
+    ln.far->allreduce_residual_rmsnorm(which, n, ln.normed, ln.resid, weight, args_.rms_norm_eps);
     return;
   }
   if (parallel_args_.world_size() > 1) parallel_args_.process_group()->allreduce(partial);
@@ -324,7 +342,7 @@ void LlamaForCausalLMHip::pre_attn(Lane& ln, size_t li, std::vector<KVCache>& kv
 }
 
 // the paged attention itself, with THIS lane's split-KV scratch
-void LlamaForCausalLMHip::attn(Lane& ln, size_t li, std::vector<KVCache>& kv) {
+void LlamaForCausalLMHip::attn(Lane& ln, size_t li, std::vector<KVCache>& kv, int phase) {
   auto [kc, vc] = kv[li].get_kv_cache();
   const auto& p = ln.params;
   slm_attn_args a{};
@@ -348,6 +366,7 @@ void LlamaForCausalLMHip::attn(Lane& ln, size_t li, std::vector<KVCache>& kv) {
   a.sm_scale = handler_->sm_scale(); a.logits_soft_cap = handler_->logits_soft_cap();
   a.sliding_window = -1;
   a.total_kv_len = p.kv_total_len > 0 && p.kv_total_len < (int64_t(1) << 31) ? static_cast<int32_t>(p.kv_total_len) : 0;
+  a.phase = phase;  // (1 / 2: the two lanes hand the KV-stream token on between the stream kernel and the combine pass)
   if (a.n_tokens == 0 || a.batch_size == 0) return;
   const size_t need = slm_paged_kv_varlen_mha_workspace_bytes(&a);
   if (need > 0) {
@@ -439,8 +458,9 @@ void LlamaForCausalLMHip::run_two_lanes(Lane& l0, Lane& l1, std::vector<KVCache>
     for (int i = 0; i < 2; ++i) {
       c10::hip::HIPStreamGuardMasqueradingAsCUDA g(streams[i]);
       if (prev != nullptr && opt_.lanes_chain) prev->block(streams[i]);
-      attn(*lanes[i], li, kv);
+      attn(*lanes[i], li, kv, /*phase=*/1);   // the KV stream: what the chain serialises
       prev = record(streams[i]);
+      attn(*lanes[i], li, kv, /*phase=*/2);   // the split-KV combine pass of a ragged batch: outside the chain
       post_attn(*lanes[i], li);
       if (li + 1 < n) pre_attn(*lanes[i], li + 1, kv);
     }

@@ -66,7 +66,10 @@ class LlamaForCausalLMHip {
 
   LlamaForCausalLMHip(const LlamaArgs& args, const QuantArgs& quant_args, const ParallelArgs& parallel_args,
                       const torch::TensorOptions& options, const Options& opt,
-                      std::shared_ptr<FusedAllReduce> fused_allreduce = nullptr);
+                      std::shared_ptr<FusedAllReduce> fused_allreduce = nullptr,
+                      // round 5: a second, independent instance for lane 1 lets a tensor-parallel rank run two
+                      // lanes (each lane's reductions meet the peers' same lane: own signal block, own buffers)
+                      std::shared_ptr<FusedAllReduce> fused_allreduce_lane1 = nullptr);
 
   // HuggingFace names, as the reference's loaders feed them (llama.h:64-121 register_module names):
   //   model.embed_tokens.weight, model.norm.weight, lm_head.weight,
@@ -102,6 +105,7 @@ class LlamaForCausalLMHip {
   };
   struct Lane {  // a range of token rows walking the stack on one stream with its own scratch
     int idx = 0;
+    FusedAllReduce* far = nullptr;   // this lane's fused all-reduce instance (TP), else nullptr
     int64_t r0 = 0, r1 = 0;
     torch::Tensor positions, resid, normed, qkv, attn, act, gate_up, o_buf, down_buf, q;
     InputParameters params;
@@ -112,11 +116,12 @@ class LlamaForCausalLMHip {
     int qkv_splits = 0;
   };
   StateDict select_qkv(const StateDict& layer_sd) const;
+  bool tp_lanes_ok() const;
   int64_t lane_split(int64_t T, const InputParameters& p) const;
   std::vector<Lane> make_lanes(int64_t T, const torch::Tensor& positions, const InputParameters& p);
   void run_norm(Lane& ln);
   void pre_attn(Lane& ln, size_t li, std::vector<KVCache>& kv);
-  void attn(Lane& ln, size_t li, std::vector<KVCache>& kv);
+  void attn(Lane& ln, size_t li, std::vector<KVCache>& kv, int phase = 0);
   void post_attn(Lane& ln, size_t li);
   void plain_layer(Lane& ln, size_t li, std::vector<KVCache>& kv);
   void reduce_add_norm(Lane& ln, int which, torch::Tensor& partial, const torch::Tensor& weight, int splits, int slot);
@@ -129,7 +134,7 @@ class LlamaForCausalLMHip {
   ParallelArgs parallel_args_;
   torch::TensorOptions options_;
   Options opt_;
-  std::shared_ptr<FusedAllReduce> far_;
+  std::shared_ptr<FusedAllReduce> far_, far_lane1_;
   int64_t n_heads_ = 0, n_kv_heads_ = 0;
   int64_t kv_replication_ = 0;  // world_size / n_kv_heads when KV heads are replicated, else 0
   std::unique_ptr<HipAttnHandler> handler_;

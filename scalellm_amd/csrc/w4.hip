@@ -987,7 +987,8 @@ static int gemm_impl(const slm_w4_gemm_args* a, const slm_w4_norm_prologue* np, 
   else if (pl.small)
     launch_gemm_small(kp, a->dtype, pl.ng, pl.n_nblocks * pl.n_mblocks * pl.split_k, st);
   else if (pl.m128)
-    launch_gemm_m128(kp, a->dtype, (int)a->group_size, pl.m128_wd, pl.n_nblocks * pl.split_k, st);
+    launch_gemm_m128(kp, a->dtype, (int)a->group_size, pl.m128_wd, tune_get(TUNE_W4_M128_AD, 2) == 1 ? 1 : 2,
+                     pl.n_nblocks * pl.split_k, st);
   else if (pl.mt == 16)
     launch_gemm_xl(kp, a->dtype, pl.ng, pl.n_nblocks * pl.n_mblocks * pl.split_k, st);
   else if (pl.mt == 8)

@@ -42,7 +42,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t m128_rsrc(const void* base, ui
 
 // NG: scale groups per 64-deep chunk (1: group size >= 64, 2: group size 32)
 // WD: weight ring depth in chunks (= unroll of the chunk loop; the host guarantees chunks % WD == 0)
-template <typename T, int NG, int WD>
+// AD: activation look-ahead in chunks.  1: chunk c + 1 is loaded at the top of chunk c and stored to LDS at its
+//     bottom (16 staging VGPRs; the counted wait in front of the stores sees loads issued ~one chunk = 16 MFMAs
+//     ago -- short of an L2 round trip under load).  2: chunk c + 2 is loaded at the top of chunk c and sits in
+//     registers for a whole chunk before it is stored (two staging sets, 32 VGPRs): the wait at the bottom of
+//     chunk c is for loads issued a full chunk earlier, and -- VMEM returns in order -- the weight loads issued
+//     behind them get two chunks of slack instead of one.
+template <typename T, int NG, int WD, int AD>
 __global__ void __launch_bounds__(256, 3)
 w4a16_gemm_m128_kernel(const GemmKParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -85,16 +91,16 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
   const uint32_t sz_voff = (uint32_t)(ntile * 32 + (lane & 31)) * 4u;
   const uint32_t sz_stride = (uint32_t)p.N * 4u;
 
-  u32x4 areg[4];
-  auto a_load = [&](int c) {  // chunk c (absolute, 64-deep) -> registers
+  u32x4 areg[AD][4];
+  auto a_load = [&](int set, int c) {  // chunk c (absolute, 64-deep) -> staging set
     const uint32_t soff = (uint32_t)min(c, clast) * 128u;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      areg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)a_voff[i], (int)soff, 0));
+      areg[set][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)a_voff[i], (int)soff, 0));
   };
-  auto a_store = [&](int buf) {
+  auto a_store = [&](int set, int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(smem + buf * M128_BUF + a_lds[i]) = areg[i];
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(smem + buf * M128_BUF + a_lds[i]) = areg[set][i];
   };
   // weights: plain (cacheable) loads -- the other lane of the decode step re-reads the layer within
   // ~0.4 ms and finds it in the Infinity Cache (w4.hip, round 4)
@@ -129,14 +135,15 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
 
   // ---- prologue: ring filled in steady-state order, chunk c0 staged ------------------------------
   if (nc > 0) {
-    a_load(c0);
+    a_load(0, c0);
 #pragma unroll
     for (int d = 0; d < WD; ++d) {
       wring[d] = w_load(c0 + d);
 #pragma unroll
       for (int g = 0; g < NG; ++g) szr[d][g] = sz_load(c0 + d, g);
     }
-    a_store(0);
+    a_store(0, 0);
+    if constexpr (AD == 2) a_load(1, c0 + 1);   // (sub-iteration u finds chunk c + 1 in set (u + 1) & 1)
     bfrag[0] = dequant(wring[0], szr[0], 0);
   }
   __syncthreads();
@@ -150,7 +157,8 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
     for (int u = 0; u < WD; ++u) {
       const int c = c0 + cb + u;        // this chunk; its weights sit in ring slot u
       const int buf = u & 1;            // (WD is even: the buffer parity is static too)
-      a_load(c + 1);                    // (past the range: clamped reload, stored but never read)
+      // (past the range: clamped reloads, stored but never read)
+      if constexpr (AD == 2) a_load(u & 1, c + 2); else a_load(0, c + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -180,7 +188,7 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      a_store(buf ^ 1);
+      a_store(AD == 2 ? ((u + 1) & 1) : 0, buf ^ 1);
       __syncthreads();
     }
   }
@@ -234,23 +242,26 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
 }
 
 template <typename T>
-static void launch_m128_t(const GemmKParams& kp, int ng, int wd, int n_blocks, hipStream_t st) {
+static void launch_m128_t(const GemmKParams& kp, int ng, int wd, int ad, int n_blocks, hipStream_t st) {
   const dim3 grid((unsigned)n_blocks), blk(256);
   const size_t lds = 2 * M128_BUF;
-#define SLM_M128(NGG, WDD) hipLaunchKernelGGL((w4a16_gemm_m128_kernel<T, NGG, WDD>), grid, blk, lds, st, kp)
-  if (ng == 2) {
-    if (wd == 4) SLM_M128(2, 4); else SLM_M128(2, 2);
+#define SLM_M128(NGG, WDD, ADD) \
+  hipLaunchKernelGGL((w4a16_gemm_m128_kernel<T, NGG, WDD, ADD>), grid, blk, lds, st, kp)
+  if (ad == 2) {
+    if (ng == 2) { if (wd == 4) SLM_M128(2, 4, 2); else SLM_M128(2, 2, 2); }
+    else { if (wd == 4) SLM_M128(1, 4, 2); else SLM_M128(1, 2, 2); }
   } else {
-    if (wd == 4) SLM_M128(1, 4); else SLM_M128(1, 2);
+    if (ng == 2) { if (wd == 4) SLM_M128(2, 4, 1); else SLM_M128(2, 2, 1); }
+    else { if (wd == 4) SLM_M128(1, 4, 1); else SLM_M128(1, 2, 1); }
   }
 #undef SLM_M128
 }
 
 // group_size 32 -> two scale groups per 64-deep chunk; chunks (64-deep) per split must be a multiple of wd
-void launch_gemm_m128(const GemmKParams& kp, int dtype, int group_size, int wd, int n_blocks, hipStream_t st) {
+void launch_gemm_m128(const GemmKParams& kp, int dtype, int group_size, int wd, int ad, int n_blocks, hipStream_t st) {
   const int ng = group_size == 32 ? 2 : 1;
-  if (dtype == SLM_BF16) launch_m128_t<bf16_tag>(kp, ng, wd, n_blocks, st);
-  else launch_m128_t<f16_tag>(kp, ng, wd, n_blocks, st);
+  if (dtype == SLM_BF16) launch_m128_t<bf16_tag>(kp, ng, wd, ad, n_blocks, st);
+  else launch_m128_t<f16_tag>(kp, ng, wd, ad, n_blocks, st);
 }
 
 }  // namespace slm

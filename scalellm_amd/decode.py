@@ -389,6 +389,68 @@ class LlamaDecodeStep:
                    getattr(params, "kv_total_len", 0) == n_seqs * params.kv_max_seq_len)
         return lanes, bool(uniform)
 
+    def probe_lanes(self, n_tokens: int, kv_len: int, n_layers: int = 8, reps: int = 3):
+        """START-UP probe of the lane policy (round 5): time the first `n_layers` decoder layers (the stack alone:
+        no embedding, no lm_head -- they cost a 2-layer probe more than the layers and drown the signal) of a uniform
+        pure-decode batch (n_tokens sequences x kv_len tokens, synthetic block table over this model's own KV
+        cache) as ONE lane and as TWO, each captured into a hipGraph and replayed `reps` times, and record
+        the pair with slm_decode_lane_policy_record -- the automatic policy then decides batches of this size
+        near this context length from the measurement instead of the Llama-3-8B constants.  ~0.2 s.
+        Call it before serving: the probe appends one synthetic token per sequence to the cache (the rows it
+        writes are saved and restored).  Returns (one_lane_us, two_lane_us) or None when two lanes cannot
+        run here (tensor-parallel rank without a per-lane all-reduce, fewer than 64 tokens, cache too small)."""
+        from . import _lib
+        ar = self.custom_ar if self.pa.world_size > 1 else None
+        q = lane_query(self.shape, self.n_heads, self.n_kv_heads, self.pa.world_size, 1, n_tokens, n_tokens, 1,
+                       kv_len, self._tp_lanes_ok())
+        if ar is not None or not self._tp_lanes_ok() or int(_lib.lib().slm_decode_lane_split(q)) <= 0:
+            return None   # (with the fused all-reduce the probe would need every rank in lock step: not here)
+        B = self.block_size
+        cache_blocks = self.layers[0]["kv"].key_cache.size(0) // B
+        if n_tokens * ((kv_len + B - 1) // B) + 2 > cache_blocks or n_tokens > self.buf["resid"].size(0):
+            return None
+        tokens, positions, params, _ = make_decode_inputs(n_tokens, kv_len, B, self.device, seed=4321,
+                                                          vocab=self.shape.vocab)
+        all_layers, k = self.layers, max(1, min(n_layers, len(self.layers)))
+        slots = params.new_cache_slots.long()
+        saved = [(L["kv"].key_cache[slots].clone(), L["kv"].value_cache[slots].clone()) for L in all_layers[:k]]
+        times = {}
+        try:
+            self.layers = all_layers[:k]
+            self.reserve_workspaces(n_tokens, kv_len)
+            o_buf, down_buf = self.buf["o"][:n_tokens], self.buf["down"][:n_tokens]
+            self.buf["resid"][:n_tokens].normal_()
+            for lanes in (1, 2):
+                with self.graph_variant((lanes, True)):
+                    self._run_layers(n_tokens, positions, params, o_buf, down_buf, None)   # warm-up outside capture
+                    torch.cuda.synchronize(self.device)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._run_layers(n_tokens, positions, params, o_buf, down_buf, None)
+                    g.replay()
+                    torch.cuda.synchronize(self.device)
+                    ts = []
+                    for _ in range(reps):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        g.replay()
+                        e1.record()
+                        e1.synchronize()
+                        ts.append(e0.elapsed_time(e1) * 1e3)
+                    times[lanes] = sorted(ts)[len(ts) // 2]
+                    del g
+        finally:
+            self.layers = all_layers
+            for L, (k0, v0) in zip(all_layers[:k], saved):
+                L["kv"].key_cache[slots] = k0
+                L["kv"].value_cache[slots] = v0
+        q.lanes_min = -1
+        _lib.check(_lib.lib().slm_decode_lane_policy_record(q, float(times[1]), float(times[2])),
+                   "slm_decode_lane_policy_record")
+        self.last_probe = dict(n_tokens=n_tokens, kv_len=kv_len, layers=k, one_lane_us=round(times[1], 1),
+                               two_lane_us=round(times[2], 1))
+        return times[1], times[2]
+
     @contextlib.contextmanager
     def graph_variant(self, variant):
         """Pin the step to `variant`'s lane count (while its graph is captured)."""
@@ -497,8 +559,8 @@ class LlamaDecodeStep:
         ln.q = self.attn.append(q, k, v, ln.positions, L["kv"], ln.params,
                                 qkv_partials=L["qkv"].deferred if self.defer_splitk else None)
 
-    def _attn(self, ln, li: int) -> None:
-        self.attn.decode(ln.q, self.layers[li]["kv"], ln.params, output=ln.attn)
+    def _attn(self, ln, li: int, phase: int = 0) -> None:
+        self.attn.decode(ln.q, self.layers[li]["kv"], ln.params, output=ln.attn, phase=phase)
 
     def _post_attn(self, ln, li: int) -> None:
         """o_proj -> (reduce) + residual + post-attention norm -> gate_up . SiLU*mul -> down ->
@@ -551,9 +613,13 @@ class LlamaDecodeStep:
                 with on(ln):
                     if prev is not None and self.lanes_chain:
                         ln.stream.wait_event(prev)
-                    self._attn(ln, li)
+                    # the KV STREAM is what the chain serialises: the token is handed on right behind the
+                    # stream kernel, the split-KV combine pass of a ragged batch (round 5: ~5 us that only
+                    # reads this lane's partials) runs outside the chained section
+                    self._attn(ln, li, phase=1)
                     prev = torch.cuda.Event()
                     prev.record(ln.stream)
+                    self._attn(ln, li, phase=2)
                     self._post_attn(ln, li)
                     if li + 1 < n:
                         self._pre_attn(ln, li + 1)
@@ -564,6 +630,25 @@ class LlamaDecodeStep:
         join = torch.cuda.Event()
         join.record(side)
         main.wait_event(join)
+
+    def _run_layers(self, T: int, positions, params: InputParameters, o_buf, down_buf, ar) -> None:
+        """The decoder stack over rows [0, T) of the static buffers (residual stream in buf["resid"]): one lane
+        or two, final norm included -- everything of a step between the embedding and the lm_head."""
+        fold = self.fold_norm and self.pa.world_size == 1 and T <= 4
+        lanes = self._make_lanes(T, positions, params, o_buf, down_buf, ar, fold)
+        self.last_lanes = len(lanes)
+        if len(lanes) == 2:
+            self._run_two_lanes(lanes[0], lanes[1])
+        else:
+            ln = lanes[0]
+            self._first_norm(ln)
+            for li in range(len(self.layers)):
+                self._pre_attn(ln, li)
+                self._attn(ln, li)
+                self._post_attn(ln, li)
+        for ln in lanes:
+            if ln.pend is not None:  # the final norm has no projection of ours behind it
+                self._run_norm(ln, ln.pend)
 
     def forward(self, tokens: torch.Tensor, positions: torch.Tensor, params: InputParameters,
                 return_logits: bool = False) -> torch.Tensor:
@@ -592,21 +677,7 @@ class LlamaDecodeStep:
             resid.copy_(x)
             o_buf, down_buf = b["o"][:T], b["down"][:T]
 
-        fold = self.fold_norm and pa.world_size == 1 and T <= 4
-        lanes = self._make_lanes(T, positions, params, o_buf, down_buf, ar, fold)
-        self.last_lanes = len(lanes)
-        if len(lanes) == 2:
-            self._run_two_lanes(lanes[0], lanes[1])
-        else:
-            ln = lanes[0]
-            self._first_norm(ln)
-            for li in range(len(self.layers)):
-                self._pre_attn(ln, li)
-                self._attn(ln, li)
-                self._post_attn(ln, li)
-        for ln in lanes:
-            if ln.pend is not None:  # the final norm has no projection of ours behind it
-                self._run_norm(ln, ln.pend)
+        self._run_layers(T, positions, params, o_buf, down_buf, ar)
         last = (params.q_cu_seq_lens[1:] - 1).long()
         self.last_hidden = normed[last]  # final-norm output of each sequence's last token (tests)
         logits = self.last_hidden @ self.lm_head  # plain library GEMM (hipBLASLt): not on the graded path

@@ -250,6 +250,8 @@ def paged_kv_varlen_mha(
     num_splits: int = 0,          # extension: 0 = heuristic, >0 forces the split-KV count
     total_kv_len: int = 0,        # extension: kv_cu_lens[batch] if the HOST knows it (a scheduling hint like
                                   # max_kv_len, slm_attn_args::total_kv_len), 0 = unknown
+    phase: int = 0,               # extension: 0 = the whole call, 1 = everything but the split-KV combine pass,
+                                  # 2 = the combine pass only (slm_attn_args::phase; 1 then 2 == 0)
 ) -> None:
     """Mirror of llm::paged_kv_varlen_mha (attn_api.h:12-27): writes `out` in place, async
     on the current stream."""
@@ -258,6 +260,7 @@ def paged_kv_varlen_mha(
                    block_cu_lens, alibi_slopes, block_size, max_q_len, max_kv_len, sm_scale,
                    logits_soft_cap, sliding_window, num_splits)
     a.total_kv_len = int(total_kv_len) if 0 < int(total_kv_len) < 2 ** 31 else 0
+    a.phase = int(phase)
     if a.n_tokens == 0 or a.batch_size == 0:
         return
     need = L.slm_paged_kv_varlen_mha_workspace_bytes(C.byref(a))

@@ -110,7 +110,7 @@ class HipAttnHandler:
             kernels.set_kv_cache(input_params.new_cache_slots, key, value, kc, vc)
 
     def batch_decode(self, query, kv_cache: KVCache, input_params: InputParameters,
-                     sliding_window: int, output: torch.Tensor) -> None:
+                     sliding_window: int, output: torch.Tensor, phase: int = 0) -> None:
         kc, vc = kv_cache.get_kv_cache()
         kernels.paged_kv_varlen_mha(output, query, kc, vc, input_params.q_cu_seq_lens,
                                     input_params.kv_cu_seq_lens, input_params.block_tables,
@@ -118,7 +118,7 @@ class HipAttnHandler:
                                     kv_cache.block_size(), input_params.q_max_seq_len,
                                     input_params.kv_max_seq_len, self.sm_scale,
                                     self.logits_soft_cap, sliding_window,
-                                    total_kv_len=getattr(input_params, "kv_total_len", 0))
+                                    total_kv_len=getattr(input_params, "kv_total_len", 0), phase=phase)
 
 
 class Attention:
@@ -143,12 +143,12 @@ class Attention:
         return q
 
     def decode(self, q, kv_cache: KVCache, input_params: InputParameters,
-               output: Optional[torch.Tensor] = None):
+               output: Optional[torch.Tensor] = None, phase: int = 0):
         """Second half of forward(): the paged attention itself (attention.cpp:41-42)."""
         T = q.size(0)
         if output is None:
             output = torch.empty(T, self.n_heads, self.head_dim, dtype=q.dtype, device=q.device)
-        self.handler.batch_decode(q, kv_cache, input_params, self.sliding_window, output)
+        self.handler.batch_decode(q, kv_cache, input_params, self.sliding_window, output, phase=phase)
         return output.view(T, self.n_heads * self.head_dim)
 
     def forward(self, query, key, value, positions, kv_cache: KVCache,

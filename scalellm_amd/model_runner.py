@@ -44,6 +44,11 @@ class ModelRunnerOptions:
     cuda_graph_max_seq_len: int = 2048
     cuda_graph_batch_sizes: List[int] = field(default_factory=list)
     num_decoding_tokens: int = 1
+    # extension (round 5): context lengths at which capture_cuda_graphs() runs the model's start-up lane
+    # probe for the captured batch size (LlamaDecodeStep.probe_lanes: the same layers timed as one lane and
+    # as two; recorded in the library's policy table), so that the one-lane / two-lane variant a replayed
+    # batch gets is a MEASURED decision near its real context length.  Empty = the policy's constants.
+    lane_probe_lengths: List[int] = field(default_factory=list)
 
 
 class _Graph:
@@ -169,6 +174,10 @@ class ModelRunner:
             return
         if batch_size > self.max_batch_size:
             raise ValueError("batch size too big")
+        if self.options.num_decoding_tokens == 1 and hasattr(self.model, "probe_lanes"):
+            for kv_len in self.options.lane_probe_lengths:   # (engine warm-up: the cache holds nothing yet)
+                if 0 < kv_len <= self.options.cuda_graph_max_seq_len:
+                    self.model.probe_lanes(batch_size, kv_len)
         g = _Graph(self, batch_size)
         g.capture(self._run)
         self.graphs[batch_size] = g

@@ -208,3 +208,48 @@ def test_two_lane_policy_table():
     assert two_lane_split(s8, 32, 8, 1, 64, 100, 100, 1, 16) == 64
     assert two_lane_split(s8, 32, 8, 1, 200, 192, 192, 1, 4096) == 0
     assert two_lane_split(s8, 32, 8, 1, 1, 48, 48, 1, 4096) == 0
+
+
+def test_lane_policy_measurements_override_the_constants():
+    """Round 5: the rule lives in the C ABI (slm_decode_lane_split) -- ONE source for the Python mirror and the
+    C++ host step -- and a recorded start-up measurement (LlamaDecodeStep.probe_lanes) decides a batch size
+    near the measured context length instead of the Llama-3-8B constants; tensor-parallel ranks only with
+    lane-safe reductions."""
+    from scalellm_amd import _lib
+    from scalellm_amd.decode import LlamaShape, lane_query, two_lane_split
+    L = _lib.lib()
+    s8, s70 = LlamaShape.llama3_8b(), LlamaShape.llama3_70b()
+    L.slm_decode_lane_policy_clear()
+    try:
+        q = lane_query(s70, 64, 8, 1, -1, 128, 128, 1, 4096)
+        assert L.slm_decode_lane_policy_measured(q) == 0
+        assert two_lane_split(s70, 64, 8, 1, -1, 128, 128, 1, 4096) == 0            # the constants: KV < 8 x weights
+        _lib.check(L.slm_decode_lane_policy_record(q, 1000.0, 900.0), "record")     # measured: two lanes 10 % faster
+        assert L.slm_decode_lane_policy_measured(q) == 1
+        assert two_lane_split(s70, 64, 8, 1, -1, 128, 128, 1, 4096) == 64
+        assert two_lane_split(s70, 64, 8, 1, -1, 128, 128, 1, 5000) == 64           # within a factor 1.5 of 4096
+        assert two_lane_split(s70, 64, 8, 1, -1, 128, 128, 1, 2500) == 0            # too far (x 1.64): the constants again
+        assert two_lane_split(s70, 64, 8, 1, -1, 120, 120, 1, 4096) == 64           # same 32-row bucket as 128
+        assert two_lane_split(s70, 64, 8, 1, -1, 160, 160, 1, 4096) == 0            # another batch size: not measured
+        assert two_lane_split(s8, 32, 8, 1, -1, 128, 128, 1, 4096) == 64            # another geometry: its own rule
+        # a measurement can also switch the constants' "yes" off (two lanes within 1.5 %: not worth it)
+        q8 = lane_query(s8, 32, 8, 1, -1, 256, 256, 1, 4096)
+        _lib.check(L.slm_decode_lane_policy_record(q8, 1000.0, 990.0), "record")
+        assert two_lane_split(s8, 32, 8, 1, -1, 256, 256, 1, 4096) == 0
+        _lib.check(L.slm_decode_lane_policy_record(q8, 1000.0, 900.0), "record")    # re-measured: replaces
+        assert two_lane_split(s8, 32, 8, 1, -1, 256, 256, 1, 4096) == 128
+        # the nearest recorded context decides
+        q8s = lane_query(s8, 32, 8, 1, -1, 256, 256, 1, 3000)
+        _lib.check(L.slm_decode_lane_policy_record(q8s, 1000.0, 1100.0), "record")
+        assert two_lane_split(s8, 32, 8, 1, -1, 256, 256, 1, 3200) == 0 and two_lane_split(s8, 32, 8, 1, -1, 256, 256, 1, 3900) == 128
+        # hard conditions hold whatever was measured: not pure decode, forced off, TP without lane-safe reductions
+        assert two_lane_split(s8, 32, 8, 1, -1, 256, 64, 4, 4096) == 0
+        assert two_lane_split(s8, 32, 8, 1, 0, 256, 256, 1, 4096) == 0
+        qt = lane_query(s8, 4, 1, 8, -1, 256, 256, 1, 4096, tp_lanes_ok=True)
+        _lib.check(L.slm_decode_lane_policy_record(qt, 1000.0, 800.0), "record")
+        assert two_lane_split(s8, 4, 1, 8, -1, 256, 256, 1, 4096, tp_lanes_ok=True) == 128
+        assert two_lane_split(s8, 4, 1, 8, -1, 256, 256, 1, 4096, tp_lanes_ok=False) == 0
+        assert two_lane_split(s8, 4, 1, 8, 64, 256, 256, 1, 4096, tp_lanes_ok=True) == 128   # forced, lane-safe
+    finally:
+        L.slm_decode_lane_policy_clear()
+    assert two_lane_split(s70, 64, 8, 1, -1, 128, 128, 1, 4096) == 0
