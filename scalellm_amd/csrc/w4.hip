@@ -734,7 +734,9 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   // instruction count (tools/probe_corun.py), and the plan with fewer, longer workgroups leaves the chain
   // longer.  SLM_W4_M128 = 1 forces it everywhere (tests), 0 disables it.
   const int m128_mode = tune_get(TUNE_W4_M128, -1);
-  if (m128_mode != 0 && (m128_mode > 0 || a->K >= 8192) && a->M > 64 && a->M <= 128 && !pl->gemv && !pl->ks &&
+  // ... and wide enough to fill the chip with 128-column tiles (>= 64 of them): the TP = 8 shards of the 70B
+  // layers (8192 x 1280, 8192 x 7168) stay on twice as many BM = 64 tiles (rank-0 shard step 11.97 vs 12.11 ms)
+  if (m128_mode != 0 && (m128_mode > 0 || (a->K >= 8192 && a->N >= 8192)) && a->M > 64 && a->M <= 128 && !pl->gemv && !pl->ks &&
       !tune_is_set(TUNE_W4_MT) &&
       a->K * a->N / 2 < ((int64_t)1 << 32) && (a->K / gs) * a->N * 4 < ((int64_t)1 << 32) &&
       ((a->M - 1) * a->lda + a->K) * 2 < ((int64_t)1 << 31)) {
