@@ -41,7 +41,7 @@ enum TuneKey : int {
   TUNE_W4_M128,           // SLM_W4_M128           w4_m128.hip at 65 <= M <= 128: 1 = always, 0 = never (default: K >= 8192)
   TUNE_W4_M128_WD,        // SLM_W4_M128_WD        weight ring depth of w4_m128.hip in 64-deep chunks (2 / 4)
   TUNE_W4_M128_SPLITS,    // SLM_W4_M128_SPLITS    workgroups w4_m128.hip's split-K aims at (default 512 = two per CU)
-  TUNE_W4_M128_AD,        // SLM_W4_M128_AD        activation look-ahead of w4_m128.hip in chunks (1 / 2, default 2)
+  TUNE_W4_M128_KW,        // SLM_W4_M128_KW        waves per column tile of w4_m128.hip (1 / 2; default: by grid size)
   TUNE_W4_SPLIT_TARGET,   // SLM_W4_SPLIT_TARGET   workgroups the general kernel's split-K aims at for M > 64 (default 512)
   TUNE_COUNT
 };

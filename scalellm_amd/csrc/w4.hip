@@ -517,7 +517,7 @@ constexpr bool w4_pre_fits(int /*mt*/, int ntw, int ng, int pc) { return !(ntw =
 struct GemmPlan {
   int mt, ntw, ng, pc, post, small, gemv, split_k, chunks_per_split, n_mblocks, n_nblocks;
   int ks, ks_cw, ks_nw, ks_tpw, ks_mt;  // K-sliced small-M kernel (w4_ks.hip)
-  int m128, m128_wd;                    // 65 <= M <= 128 kernel (w4_m128.hip)
+  int m128, m128_wd, m128_kw;           // 65 <= M <= 128 kernel (w4_m128.hip)
   size_t lds_bytes, part_bytes, aperm_bytes;
 };
 
@@ -727,6 +727,7 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   // workgroups per CU with >= 512 of K each (the consumers take up to 16 slabs).
   pl->m128 = 0;
   pl->m128_wd = 2;
+  pl->m128_kw = 1;
   // Where (measured, profiles/r05_m128_*.jsonl): deep-K layers (K >= 8192: the Llama-3-70B shapes, where the
   // general kernel already took its ~200-VGPR BM = 128 tiles) -- the 70B step 50.6 -> 49.4 ms.  On the
   // Llama-3-8B shapes (K = 4096, and 14336 x 4096) it ties the BM = 64 general kernel alone and in the two-lane
@@ -761,6 +762,11 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
     int wd = tune_get(TUNE_W4_M128_WD, a->K >= 8192 ? 4 : 2);
     if (wd != 4 || (2 * per) % 4 != 0 || n_chunks % per != 0) wd = 2;
     pl->m128_wd = wd;
+    // two waves per column tile (512-thread workgroups) up to two workgroups per CU: measured on the 70B shapes
+    // (profiles/r05_m128_kw.jsonl, one box): layer 333 -> 313 us, gate_up 155 -> 148 (448 workgroups), the others
+    // within 1 us (480 / 512 workgroups).  SLM_W4_M128_KW: 1 / 2 force a form.
+    const int kw_knob = tune_get(TUNE_W4_M128_KW, 0);
+    pl->m128_kw = kw_knob == 2 || (kw_knob != 1 && (int64_t)pl->n_nblocks * pl->split_k <= 512) ? 2 : 1;
     pl->lds_bytes = W4_M128_LDS_BYTES;
   }
   pl->part_bytes = pl->split_k > 1 ? (size_t)pl->split_k * a->M * a->N * sizeof(float) : 0;
@@ -989,8 +995,7 @@ static int gemm_impl(const slm_w4_gemm_args* a, const slm_w4_norm_prologue* np, 
   else if (pl.small)
     launch_gemm_small(kp, a->dtype, pl.ng, pl.n_nblocks * pl.n_mblocks * pl.split_k, st);
   else if (pl.m128)
-    launch_gemm_m128(kp, a->dtype, (int)a->group_size, pl.m128_wd, tune_get(TUNE_W4_M128_AD, 2) == 1 ? 1 : 2,
-                     pl.n_nblocks * pl.split_k, st);
+    launch_gemm_m128(kp, a->dtype, (int)a->group_size, pl.m128_wd, pl.m128_kw, pl.n_nblocks * pl.split_k, st);
   else if (pl.mt == 16)
     launch_gemm_xl(kp, a->dtype, pl.ng, pl.n_nblocks * pl.n_mblocks * pl.split_k, st);
   else if (pl.mt == 8)

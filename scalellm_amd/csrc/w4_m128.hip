@@ -48,16 +48,27 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t m128_rsrc(const void* base, ui
 //     registers for a whole chunk before it is stored (two staging sets, 32 VGPRs): the wait at the bottom of
 //     chunk c is for loads issued a full chunk earlier, and -- VMEM returns in order -- the weight loads issued
 //     behind them get two chunks of slack instead of one.
-template <typename T, int NG, int WD, int AD>
-__global__ void __launch_bounds__(256, 3)
+// KW: waves per column tile (1 / 2).  2 (round 5): a 512-thread workgroup whose wave pairs (w, w + 4) share a column
+//     tile and split every 64-deep chunk between them -- wave w takes k-steps 0, 1 (the first 8 bytes of the lane's
+//     weight vector), wave w + 4 k-steps 2, 3 -- each with its own accumulators, summed once through LDS at the end.
+//     Same tile, same bytes, same instructions in total; but a launch whose grid gives a CU ONE workgroup (gate_up at
+//     M = 128: 224 tiles on 256 CUs) now has two waves per SIMD to overlap each other's LDS / VMEM waits and MFMA
+//     phases instead of one.
+template <typename T, int NG, int WD, int AD, int KW>
+__global__ void __launch_bounds__(256 * KW, KW == 2 ? 2 : 3)
 w4a16_gemm_m128_kernel(const GemmKParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Mfma<T>::frag frag_t;
   constexpr int MT = 4;
+  constexpr int NT = 256 * KW;     // threads
+  constexpr int AI = 4 / KW;       // 16-B activation items per thread and chunk
+  constexpr int JW = 4 / KW;       // k-steps (weight words) per wave and chunk
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave & 3;         // column tile of the workgroup
+  const int kw = wave >> 2;        // k part of the chunk (0 when KW == 1)
   const int nb = (int)(blockIdx.x % (unsigned)p.n_nblocks);
   const int ks = (int)(blockIdx.x / (unsigned)p.n_nblocks);
   // split-K ranges are planned in 128-deep units (W4_KC); this loop walks 64-deep chunks
@@ -67,7 +78,7 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
   const int clast = 2 * p.n_chunks - 1;
 
   const int n_tiles = (int)(p.N / 32);
-  const int gt = nb * 4 + wave;
+  const int gt = nb * 4 + ct;
   const bool nvalid = gt < n_tiles;
   const int ntile = nvalid ? gt : n_tiles - 1;  // (clamped: computes on the last valid tile, no store)
 
@@ -76,40 +87,52 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
   const __amdgpu_buffer_rsrc_t w_rs = m128_rsrc(p.wq, (uint32_t)((uint64_t)p.K * p.N / 2));
   const __amdgpu_buffer_rsrc_t sz_rs = m128_rsrc(p.sz, (uint32_t)((uint64_t)p.ks_groups * p.N * 4));
 
-  // activations: thread -> 4 x (row, 16-B slot) of the 128 x 64 tile
-  uint32_t a_voff[4], a_lds[4];
+  // activations: thread -> AI x (row, 16-B slot) of the 128 x 64 tile
+  uint32_t a_voff[AI], a_lds[AI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + 256 * i;
+  for (int i = 0; i < AI; ++i) {
+    const int idx = tid + NT * i;
     const int row = idx >> 3, slot = idx & 7;
     const int rc = row < p.M ? row : (int)p.M - 1;  // rows >= M: clamped duplicates, never stored
     a_voff[i] = (uint32_t)(2 * (rc * (int)p.lda + slot * 8));
     a_lds[i] = (uint32_t)(row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
   }
-  const uint32_t w_voff = (uint32_t)ntile * 1024u + (uint32_t)lane * 16u;
+  // this wave's JW words of the lane's 16-B weight vector: bytes [8 kw, 8 kw + 4 JW)
+  const uint32_t w_voff = (uint32_t)ntile * 1024u + (uint32_t)lane * 16u + (uint32_t)kw * (4u * JW);
   const uint32_t kt_stride = (uint32_t)n_tiles * 1024u;  // bytes per 64-deep kt block row
   const uint32_t sz_voff = (uint32_t)(ntile * 32 + (lane & 31)) * 4u;
   const uint32_t sz_stride = (uint32_t)p.N * 4u;
 
-  u32x4 areg[AD][4];
+  u32x4 areg[AD][AI];
   auto a_load = [&](int set, int c) {  // chunk c (absolute, 64-deep) -> staging set
     const uint32_t soff = (uint32_t)min(c, clast) * 128u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < AI; ++i)
       areg[set][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)a_voff[i], (int)soff, 0));
   };
   auto a_store = [&](int set, int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(smem + buf * M128_BUF + a_lds[i]) = areg[set][i];
+    for (int i = 0; i < AI; ++i) *reinterpret_cast<u32x4*>(smem + buf * M128_BUF + a_lds[i]) = areg[set][i];
   };
   // weights: plain (cacheable) loads -- the other lane of the decode step re-reads the layer within
   // ~0.4 ms and finds it in the Infinity Cache (w4.hip, round 4)
-  auto w_load = [&](int c) -> u32x4 {
-    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                         w_rs, (int)w_voff, (int)((uint32_t)min(c, clast) * kt_stride), 0));
+  struct WVec { uint32_t w[JW]; };
+  auto w_load = [&](int c) -> WVec {
+    WVec v;
+    const int soff = (int)((uint32_t)min(c, clast) * kt_stride);
+    if constexpr (KW == 1) {
+      const u32x4 t = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, (int)w_voff, soff, 0));
+      v.w[0] = t.x; v.w[1] = t.y; v.w[2] = t.z; v.w[3] = t.w;
+    } else {
+      const u32x2 t = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(w_rs, (int)w_voff, soff, 0));
+      v.w[0] = t.x; v.w[1] = t.y;
+    }
+    return v;
   };
+  // scale / zero words this wave needs per chunk: one per scale group its k-steps touch
+  constexpr int NGW = (NG == 2 && KW == 1) ? 2 : 1;
   auto sz_load = [&](int c, int g) -> uint32_t {
-    const uint32_t k = (uint32_t)min(c, clast) * 64u + (uint32_t)g * 32u;
+    const uint32_t k = (uint32_t)min(c, clast) * 64u + (uint32_t)(KW == 2 ? kw : g) * 32u;
     const uint32_t grp = p.gs_shift >= 30 ? 0u : (k >> p.gs_shift);
     return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(sz_rs, (int)sz_voff, (int)(grp * sz_stride), 0);
   };
@@ -120,15 +143,14 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
-  u32x4 wring[WD];
-  uint32_t szr[WD][NG];
+  WVec wring[WD];
+  uint32_t szr[WD][NGW];
   frag_t bfrag[2];
 
-  auto dequant = [&](const u32x4 wv, const uint32_t (&sz)[NG], int j) -> frag_t {
-    const uint32_t word = j == 0 ? wv.x : j == 1 ? wv.y : j == 2 ? wv.z : wv.w;
-    const W4Dq<T> dq(sz[NG == 2 ? (j >> 1) : 0]);
+  auto dequant = [&](const WVec& wv, const uint32_t (&sz)[NGW], int jj) -> frag_t {  // jj: word of THIS wave
+    const W4Dq<T> dq(sz[NGW == 2 ? (jj >> 1) : 0]);
     uint32_t o[4];
-    dq.word(word, o);
+    dq.word(wv.w[jj], o);
     const u32x4 packed = {o[0], o[1], o[2], o[3]};
     return __builtin_bit_cast(frag_t, packed);
   };
@@ -140,7 +162,7 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
     for (int d = 0; d < WD; ++d) {
       wring[d] = w_load(c0 + d);
 #pragma unroll
-      for (int g = 0; g < NG; ++g) szr[d][g] = sz_load(c0 + d, g);
+      for (int g = 0; g < NGW; ++g) szr[d][g] = sz_load(c0 + d, g);
     }
     a_store(0, 0);
     if constexpr (AD == 2) a_load(1, c0 + 1);   // (sub-iteration u finds chunk c + 1 in set (u + 1) & 1)
@@ -151,6 +173,7 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
   const int mrow = lane & 31, kh = lane >> 5;
   const uint32_t fr_base = (uint32_t)(mrow * 128);
   const uint32_t fr_x = (uint32_t)((mrow >> 1) & 7);
+  const uint32_t slot0 = (uint32_t)(2 * JW * kw + kh);   // 16-B slot of this wave's first k-step
 
   for (int cb = 0; cb < nc; cb += WD) {
 #pragma unroll
@@ -161,30 +184,27 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
       if constexpr (AD == 2) a_load(u & 1, c + 2); else a_load(0, c + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int cur = j & 1, nxt = cur ^ 1;
-        const int slot = 2 * j + kh;
+      for (int jj = 0; jj < JW; ++jj) {
+        const int cur = jj & 1, nxt = cur ^ 1;
+        const uint32_t slot = slot0 + 2u * jj;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          const uint32_t off = (uint32_t)(buf * M128_BUF + m * 32 * 128) + fr_base +
-                               (((uint32_t)slot ^ fr_x) << 4);
+          const uint32_t off = (uint32_t)(buf * M128_BUF + m * 32 * 128) + fr_base + ((slot ^ fr_x) << 4);
           const frag_t af = __builtin_bit_cast(frag_t, *reinterpret_cast<const u32x4*>(smem + off));
           acc[m] = Mfma<T>::run(af, bfrag[cur], acc[m]);
         }
         // the next k-step's B fragment in the shadow of the MFMAs above
-        if (j < 3) {
-          bfrag[nxt] = dequant(wring[u], szr[u], j + 1);
+        if (jj < JW - 1) {
+          bfrag[nxt] = dequant(wring[u], szr[u], jj + 1);
         } else {
           const int un = (u + 1) % WD;
           bfrag[nxt] = dequant(wring[un], szr[un], 0);
-        }
-        if (j == 3) {
-          // ring slot u is free (its last word was dequantised under k-step 2): re-issue it WD chunks
-          // ahead, AFTER this iteration's activation loads (older in the vmcnt queue)
+          // ring slot u is free (its last word was dequantised under the previous k-step): re-issue it WD
+          // chunks ahead, AFTER this iteration's activation loads (older in the vmcnt queue)
           __builtin_amdgcn_sched_barrier(0);
           wring[u] = w_load(c + WD);
 #pragma unroll
-          for (int g = 0; g < NG; ++g) szr[u][g] = sz_load(c + WD, g);
+          for (int g = 0; g < NGW; ++g) szr[u][g] = sz_load(c + WD, g);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -193,13 +213,37 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
     }
   }
 
+  // ---- KW == 2: the k parts of a column tile meet in LDS (two passes of two row tiles: 4 x 2 x 4 KiB = the
+  //      32 KiB of the activation buffers); waves 0-3 carry on with the sums
+  if constexpr (KW == 2) {
+    float* xs = reinterpret_cast<float*>(smem) + ct * (2 * 16 * 64);
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      if (kw == 1) {
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xs[(m2 * 16 + r) * 64 + lane] = acc[2 * ps + m2][r];
+      }
+      __syncthreads();
+      if (kw == 0) {
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[2 * ps + m2][r] += xs[(m2 * 16 + r) * 64 + lane];
+      }
+      __syncthreads();
+    }
+  }
+  const bool owner = kw == 0;   // the wave that holds the tile's sums
+
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   if (p.silu && p.split_k == 1) {
     // SLM_W4_SILU_MUL: column tiles are (gate, up) pairs held by waves (0, 1) and (2, 3): the up wave
     // hands its T-rounded tile to the gate wave through the (now idle) activation buffers
     const uint16_t* bias = reinterpret_cast<const uint16_t*>(p.bias);
-    uint16_t* ex = reinterpret_cast<uint16_t*>(smem) + (wave >> 1) * (MT * 1024);
-    if (wave & 1) {
+    uint16_t* ex = reinterpret_cast<uint16_t*>(smem) + (ct >> 1) * (MT * 1024);
+    if (owner && (ct & 1)) {
       const float bu = bias ? lo_f32<T>((uint32_t)bias[ntile * 32 + (lane & 31)]) : 0.f;
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -207,7 +251,7 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
         for (int r = 0; r < 16; ++r) ex[(m * 16 + r) * 64 + lane] = pack1<T>(acc[m][r] + bu);
     }
     __syncthreads();
-    if ((wave & 1) || !nvalid) return;
+    if (!owner || (ct & 1) || !nvalid) return;
     const int64_t gcol = (int64_t)ntile * 32 + (lane & 31), ocol = (int64_t)(ntile >> 1) * 32 + (lane & 31);
     const float bg = bias ? lo_f32<T>((uint32_t)bias[gcol]) : 0.f;
 #pragma unroll
@@ -222,7 +266,7 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
     }
     return;
   }
-  if (!nvalid) return;
+  if (!owner || !nvalid) return;
   const int64_t n = (int64_t)ntile * 32 + (lane & 31);
   float bv = 0.f;
   if (p.split_k == 1 && p.bias) bv = lo_f32<T>((uint32_t)reinterpret_cast<const uint16_t*>(p.bias)[n]);
@@ -241,27 +285,28 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
   }
 }
 
-template <typename T>
-static void launch_m128_t(const GemmKParams& kp, int ng, int wd, int ad, int n_blocks, hipStream_t st) {
-  const dim3 grid((unsigned)n_blocks), blk(256);
+template <typename T, int KW>
+static void launch_m128_t(const GemmKParams& kp, int ng, int wd, int n_blocks, hipStream_t st) {
+  const dim3 grid((unsigned)n_blocks), blk(256 * KW);
   const size_t lds = 2 * M128_BUF;
-#define SLM_M128(NGG, WDD, ADD) \
-  hipLaunchKernelGGL((w4a16_gemm_m128_kernel<T, NGG, WDD, ADD>), grid, blk, lds, st, kp)
-  if (ad == 2) {
-    if (ng == 2) { if (wd == 4) SLM_M128(2, 4, 2); else SLM_M128(2, 2, 2); }
-    else { if (wd == 4) SLM_M128(1, 4, 2); else SLM_M128(1, 2, 2); }
-  } else {
-    if (ng == 2) { if (wd == 4) SLM_M128(2, 4, 1); else SLM_M128(2, 2, 1); }
-    else { if (wd == 4) SLM_M128(1, 4, 1); else SLM_M128(1, 2, 1); }
-  }
+#define SLM_M128(NGG, WDD) \
+  hipLaunchKernelGGL((w4a16_gemm_m128_kernel<T, NGG, WDD, 1, KW>), grid, blk, lds, st, kp)
+  if (ng == 2) { if (wd == 4) SLM_M128(2, 4); else SLM_M128(2, 2); }
+  else { if (wd == 4) SLM_M128(1, 4); else SLM_M128(1, 2); }
 #undef SLM_M128
 }
 
-// group_size 32 -> two scale groups per 64-deep chunk; chunks (64-deep) per split must be a multiple of wd
-void launch_gemm_m128(const GemmKParams& kp, int dtype, int group_size, int wd, int ad, int n_blocks, hipStream_t st) {
+// group_size 32 -> two scale groups per 64-deep chunk; chunks (64-deep) per split must be a multiple of wd;
+// kw = waves per column tile (1: 256-thread workgroups, 2: 512-thread workgroups with the chunk split in two)
+// (The activation look-ahead of two chunks, AD = 2, measured the same as one on every shape and is not built:
+//  profiles/r05_m128_70b_shapes.jsonl.)
+void launch_gemm_m128(const GemmKParams& kp, int dtype, int group_size, int wd, int kw, int n_blocks, hipStream_t st) {
   const int ng = group_size == 32 ? 2 : 1;
-  if (dtype == SLM_BF16) launch_m128_t<bf16_tag>(kp, ng, wd, ad, n_blocks, st);
-  else launch_m128_t<f16_tag>(kp, ng, wd, ad, n_blocks, st);
+  if (dtype == SLM_BF16) {
+    if (kw == 2) launch_m128_t<bf16_tag, 2>(kp, ng, wd, n_blocks, st); else launch_m128_t<bf16_tag, 1>(kp, ng, wd, n_blocks, st);
+  } else {
+    if (kw == 2) launch_m128_t<f16_tag, 2>(kp, ng, wd, n_blocks, st); else launch_m128_t<f16_tag, 1>(kp, ng, wd, n_blocks, st);
+  }
 }
 
 }  // namespace slm

@@ -75,6 +75,9 @@ PLANS = [
     (128, 1024, 512, 128, dict(SLM_W4_M128=1, SLM_W4_M128_WD=4, SLM_W4_SPLITK=1)),  # ... four-chunk weight ring
     (65, 1024, 448, 128, dict(SLM_W4_M128=1, SLM_W4_SPLITK=1)),  # ... N = 7 tile pairs: a clamped wave pair
     (128, 8192, 1024, 128, dict()),                              # ... K >= 8192: the plan's own choice
+    (128, 2048, 1024, 128, dict(SLM_W4_M128=1, SLM_W4_M128_KW=2, SLM_W4_SPLITK=1)),  # ... two waves per column tile
+    (100, 1024, 448, 32, dict(SLM_W4_M128=1, SLM_W4_M128_KW=2, SLM_W4_SPLITK=2)),    # ... + slabs, group 32, clamped pair
+    (96, 1024, 512, 64, dict(SLM_W4_M128=1, SLM_W4_M128_KW=1, SLM_W4_SPLITK=1)),
 ]
 
 
