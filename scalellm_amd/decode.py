@@ -320,8 +320,6 @@ class LlamaDecodeStep:
             h0 = two_lane_split(s, self.n_heads, self.n_kv_heads, self.pa.world_size,
                                 self.lanes_min if self.lanes_min > 0 else 1, n_tokens, n_tokens, 1, 1 << 30,
                                 tp_lanes_ok=True)
-            if self.lanes_min < 0 and not 96 <= n_tokens <= 256:
-                h0 = 0
         for lane, rows in ((0, n_tokens), (1, n_tokens - h0)) if 0 < h0 < n_tokens else ((0, n_tokens),):
             with kernels.workspace_lane(lane):
                 kernels.reserve_workspace(need_for(rows), self.device, deferred_nbytes=16 * rows * widest * 4)
