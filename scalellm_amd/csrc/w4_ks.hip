@@ -80,7 +80,13 @@ constexpr int KS_SLOTS = 4;  // partial-tile slots in LDS (see the slot arithmet
 // for ONE chunk per wave: K is split over the 8 waves x ceil(K / 1024) workgroups (fp32 slabs, summed
 // by the consumer or the reduce kernel).  A 64 x 32 partial tile goes through the LDS meeting as two
 // consecutive entries of the slot sequence (2t, 2t + 1).
-template <typename T, int CW, int NG, int NW, bool TL = false, bool PK = false, int MT = 1>
+// AF (round 5): the activations arrive FRAGMENT-MAJOR (SLM_W4_A_FRAG: a_frag[K/16][ceil(M/32)][64 lanes][16 B], lane
+// l of block (j, mt) = row 32 mt + (l & 31), k = 16 j + 8 (l >> 5) .. + 7 -- exactly one MFMA A operand per KiB,
+// written that way by the producer: slm_rms_norm_frag, the attention and SiLU epilogues).  The prologue is then
+// 8 coalesced 1-KiB loads per chunk straight into the fragment registers: no LDS-DMA issue (32 x s_mov m0 +
+// buffer_load ... lds), no staging round trip, no fragment reads, no swizzle -- the part of the prologue that
+// took the same 8.8 k of 12.7 k cycles with every load disabled (profiles/r03_ks_timeline.jsonl).
+template <typename T, int CW, int NG, int NW, bool TL = false, bool PK = false, int MT = 1, bool AF = false>
 __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Mfma<T>::frag frag_t;
@@ -203,6 +209,51 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
   frag_t act[MT][CW][8];
   float xa[MT][NP];
   {
+    float xg[MT][2 * NP];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2 * NP; ++s2) xg[mt][s2] = 0.f;
+    }
+    auto xsum_chunk = [&](int v) {
+      const int c = v / MT, mt = v % MT;
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        float xs0 = 0.f, xs1 = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < WPG; ++jj) {
+          const u32x4 f = __builtin_bit_cast(u32x4, act[mt][c][g * WPG + jj]);
+          xs0 = dot2<T>(f.x, KsOnes<T>::bits, xs0);
+          xs1 = dot2<T>(f.y, KsOnes<T>::bits, xs1);
+          xs0 = dot2<T>(f.z, KsOnes<T>::bits, xs0);
+          xs1 = dot2<T>(f.w, KsOnes<T>::bits, xs1);
+        }
+        const float xs = xs0 + xs1;
+        xg[mt][c * NG + g] = xs + __shfl_xor(xs, 32, 64);
+      }
+    };
+    if constexpr (AF) {
+      // fragment-major activations: block (k-step J = 8 (cw0 + c) + j, row tile mt) is one contiguous KiB
+      const int mtiles = (int)((p.M + 31) >> 5);
+      const __amdgpu_buffer_rsrc_t af_rs = ks_rsrc(p.a, (uint32_t)((p.K >> 4) * (int64_t)mtiles * 1024));
+      const uint32_t af_voff = (uint32_t)lane * 16u;
+#pragma unroll
+      for (int v = 0; v < VC; ++v) {
+        const int c = v / MT, mt = v % MT;
+        const int cabs = cw0 + c;
+        const bool on = cabs <= clast && mt < mtiles && !(p.ks_dbg & 1);   // chunks past K: zeros (out-of-range loads)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t soff = on ? (uint32_t)(((cabs * 8 + j) * mtiles + mt) * 1024) : KS_OOB;
+          act[mt][c][j] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(af_rs, (int)af_voff, (int)soff, 0));
+        }
+      }
+      stamp(2);
+      // counters zeroed (top of the kernel) before anybody can publish a tile
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+      for (int v = 0; v < VC; ++v) xsum_chunk(v);
+    } else {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     // hand-made resource words for the asm DMA: base, base_hi (stride 0), bytes, flags
     const uint64_t abits = reinterpret_cast<uint64_t>(p.a);
@@ -253,29 +304,6 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
     // fp32 accumulate -- then the two k halves of a row (lanes l and l + 32) are added; every lane ends
     // with X[m = lane & 31].  (32 VALU per chunk; eight MFMAs against a ones fragment cost twice the
     // issue time and serialise on the accumulator.)
-    float xg[MT][2 * NP];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-      for (int s2 = 0; s2 < 2 * NP; ++s2) xg[mt][s2] = 0.f;
-    }
-    auto xsum_chunk = [&](int v) {
-      const int c = v / MT, mt = v % MT;
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        float xs0 = 0.f, xs1 = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < WPG; ++jj) {
-          const u32x4 f = __builtin_bit_cast(u32x4, act[mt][c][g * WPG + jj]);
-          xs0 = dot2<T>(f.x, KsOnes<T>::bits, xs0);
-          xs1 = dot2<T>(f.y, KsOnes<T>::bits, xs1);
-          xs0 = dot2<T>(f.z, KsOnes<T>::bits, xs0);
-          xs1 = dot2<T>(f.w, KsOnes<T>::bits, xs1);
-        }
-        const float xs = xs0 + xs1;
-        xg[mt][c * NG + g] = xs + __shfl_xor(xs, 32, 64);
-      }
-    };
 #pragma unroll
     for (int c0 = 0; c0 < VC; c0 += 2) {
       if (c0 > 0)  // the fragment reads of the previous pair have returned before their buffers are refilled
@@ -314,6 +342,7 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
     }
     xsum_chunk(VC >= 2 ? VC - 2 : 0);
     if (VC >= 2) xsum_chunk(VC - 1);
+    }  // (!AF)
     // the partial-slot writes of tile 0 reuse the staging memory: the fragment reads are done (their
     // values fed the MFMAs above)
 #pragma unroll
