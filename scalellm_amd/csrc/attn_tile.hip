@@ -364,12 +364,34 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
     }
+    // P as packed MFMA B fragments (the softmax registers ARE the operand order of P.V).  One-wave (verify)
+    // class, round 5: exponentiate and pack per 8-score group -- 8 floats live instead of 16, which takes the
+    // soft-cap / alibi / window instantiation from 3 spilled VGPRs to none at its 256-register cap; the
+    // multi-wave classes keep all 16 * NH scores in flight and pack inside the MFMA loop (same arithmetic, same
+    // summation order either way).
     float lsum = 0.f;
-    float sv[16 * NH];
+    u32x4 pbq[NW == 1 ? 2 * NH : 1];
+    float sv[NW == 1 ? 8 : 16 * NH];
+    if constexpr (NW == 1) {
 #pragma unroll
-    for (int r = 0; r < 16 * NH; ++r) {
-      sv[r] = fast_exp2(fmaf(sacc[r >> 4][r & 15], cmul, -m_run));
-      lsum += sv[r];
+      for (int s2 = 0; s2 < 2 * NH; ++s2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int r = 8 * s2 + e;
+          sv[e] = fast_exp2(fmaf(sacc[r >> 4][r & 15], cmul, -m_run));
+          lsum += sv[e];
+        }
+        pbq[s2].x = pack2<T>(sv[0], sv[1]);
+        pbq[s2].y = pack2<T>(sv[2], sv[3]);
+        pbq[s2].z = pack2<T>(sv[4], sv[5]);
+        pbq[s2].w = pack2<T>(sv[6], sv[7]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16 * NH; ++r) {
+        sv[r] = fast_exp2(fmaf(sacc[r >> 4][r & 15], cmul, -m_run));
+        lsum += sv[r];
+      }
     }
     lsum += __shfl_xor(lsum, 32, 64);
     l_run += lsum;
@@ -378,10 +400,14 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
 #pragma unroll
     for (int s2 = 0; s2 < 2 * NH; ++s2) {
       u32x4 pb;
-      pb.x = pack2<T>(sv[8 * s2 + 0], sv[8 * s2 + 1]);
-      pb.y = pack2<T>(sv[8 * s2 + 2], sv[8 * s2 + 3]);
-      pb.z = pack2<T>(sv[8 * s2 + 4], sv[8 * s2 + 5]);
-      pb.w = pack2<T>(sv[8 * s2 + 6], sv[8 * s2 + 7]);
+      if constexpr (NW == 1) {
+        pb = pbq[s2];
+      } else {
+        pb.x = pack2<T>(sv[8 * s2 + 0], sv[8 * s2 + 1]);
+        pb.y = pack2<T>(sv[8 * s2 + 2], sv[8 * s2 + 3]);
+        pb.z = pack2<T>(sv[8 * s2 + 4], sv[8 * s2 + 5]);
+        pb.w = pack2<T>(sv[8 * s2 + 6], sv[8 * s2 + 7]);
+      }
       const frag_t pfrag = __builtin_bit_cast(frag_t, pb);
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
