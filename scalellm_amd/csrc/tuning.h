@@ -43,6 +43,7 @@ enum TuneKey : int {
   TUNE_W4_M128_SPLITS,    // SLM_W4_M128_SPLITS    workgroups w4_m128.hip's split-K aims at (default 512 = two per CU)
   TUNE_W4_M128_KW,        // SLM_W4_M128_KW        waves per column tile of w4_m128.hip (1 / 2; default: by grid size)
   TUNE_W4_SPLIT_TARGET,   // SLM_W4_SPLIT_TARGET   workgroups the general kernel's split-K aims at for M > 64 (default 512)
+  TUNE_W4_M128_CT,        // SLM_W4_M128_CT        column tiles per workgroup of w4_m128.hip (4 = 128 columns, 8 = 256 columns)
   TUNE_COUNT
 };
 

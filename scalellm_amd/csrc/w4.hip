@@ -517,7 +517,7 @@ constexpr bool w4_pre_fits(int /*mt*/, int ntw, int ng, int pc) { return !(ntw =
 struct GemmPlan {
   int mt, ntw, ng, pc, post, small, gemv, split_k, chunks_per_split, n_mblocks, n_nblocks;
   int ks, ks_cw, ks_nw, ks_tpw, ks_mt;  // K-sliced small-M kernel (w4_ks.hip)
-  int m128, m128_wd, m128_kw;           // 65 <= M <= 128 kernel (w4_m128.hip)
+  int m128, m128_wd, m128_kw, m128_ct;  // 65 <= M <= 128 kernel (w4_m128.hip)
   size_t lds_bytes, part_bytes, aperm_bytes;
 };
 
@@ -728,6 +728,7 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   pl->m128 = 0;
   pl->m128_wd = 2;
   pl->m128_kw = 1;
+  pl->m128_ct = 4;
   // Where (measured, profiles/r05_m128_*.jsonl): deep-K layers (K >= 8192: the Llama-3-70B shapes, where the
   // general kernel already took its ~200-VGPR BM = 128 tiles) -- the 70B step 50.6 -> 49.4 ms.  On the
   // Llama-3-8B shapes (K = 4096, and 14336 x 4096) it ties the BM = 64 general kernel alone and in the two-lane
@@ -741,8 +742,13 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
       !tune_is_set(TUNE_W4_MT) &&
       a->K * a->N / 2 < ((int64_t)1 << 32) && (a->K / gs) * a->N * 4 < ((int64_t)1 << 32) &&
       ((a->M - 1) * a->lda + a->K) * 2 < ((int64_t)1 << 31)) {
-    const int64_t tiles1 = (a->N + 127) / 128;
-    const int64_t target = tune_get(TUNE_W4_M128_SPLITS, 512);
+    // 256-column workgroups (8 column tiles share the activation panel a CU ingests, w4_m128.hip "CT"): one
+    // 512-thread workgroup per CU is the fill they aim at.  Default where the plan picks this kernel itself (the
+    // deep, wide 70B shapes: layer at M = 128 306.6 -> 285.0 us, every GEMM of it faster,
+    // profiles/r05_m128_ct8.jsonl); forced onto the 8B shapes (SLM_W4_M128 = 1) the two forms tie.
+    const int ct = tune_get(TUNE_W4_M128_CT, a->K >= 8192 && a->N >= 8192 ? 8 : 4) == 8 ? 8 : 4;
+    const int64_t tiles1 = (a->N + 32 * ct - 1) / (32 * ct);
+    const int64_t target = tune_get(TUNE_W4_M128_SPLITS, ct == 8 ? 256 : 512);
     int64_t want = (target + tiles1 / 2) / tiles1;
     const int64_t cap = n_chunks / 4 > 0 ? n_chunks / 4 : 1;
     if (want > cap) want = cap;
@@ -767,6 +773,8 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
     // within 1 us (480 / 512 workgroups).  SLM_W4_M128_KW: 1 / 2 force a form.
     const int kw_knob = tune_get(TUNE_W4_M128_KW, 0);
     pl->m128_kw = kw_knob == 2 || (kw_knob != 1 && (int64_t)pl->n_nblocks * pl->split_k <= 512) ? 2 : 1;
+    pl->m128_ct = ct;
+    if (ct == 8) pl->m128_kw = 1;
     pl->lds_bytes = W4_M128_LDS_BYTES;
   }
   pl->part_bytes = pl->split_k > 1 ? (size_t)pl->split_k * a->M * a->N * sizeof(float) : 0;
@@ -995,7 +1003,7 @@ static int gemm_impl(const slm_w4_gemm_args* a, const slm_w4_norm_prologue* np, 
   else if (pl.small)
     launch_gemm_small(kp, a->dtype, pl.ng, pl.n_nblocks * pl.n_mblocks * pl.split_k, st);
   else if (pl.m128)
-    launch_gemm_m128(kp, a->dtype, (int)a->group_size, pl.m128_wd, pl.m128_kw, pl.n_nblocks * pl.split_k, st);
+    launch_gemm_m128(kp, a->dtype, (int)a->group_size, pl.m128_wd, pl.m128_kw, pl.m128_ct, pl.n_nblocks * pl.split_k, st);
   else if (pl.mt == 16)
     launch_gemm_xl(kp, a->dtype, pl.ng, pl.n_nblocks * pl.n_mblocks * pl.split_k, st);
   else if (pl.mt == 8)

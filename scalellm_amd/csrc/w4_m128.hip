@@ -54,21 +54,28 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t m128_rsrc(const void* base, ui
 //     Same tile, same bytes, same instructions in total; but a launch whose grid gives a CU ONE workgroup (gate_up at
 //     M = 128: 224 tiles on 256 CUs) now has two waves per SIMD to overlap each other's LDS / VMEM waits and MFMA
 //     phases instead of one.
-template <typename T, int NG, int WD, int AD, int KW>
-__global__ void __launch_bounds__(256 * KW, KW == 2 ? 2 : 3)
+// CT: column tiles (of 32) per workgroup: 4 (128 columns, 256 KW threads) or 8 (256 columns, 512 threads, KW = 1).
+//     What a CU ingests per output tile is the 128-row activation panel ONCE PER WORKGROUP plus the weights; at
+//     M = 128 the panel (128 x K x 2 B) is 4 x the weights of a 128-column workgroup, and the L2 -> CU path
+//     (~21 B/clk per CU) -- not HBM, not the matrix pipe -- is what a 70B-sized layer waits for (gate_up:
+//     448 workgroups x 2.5 MB = 1.17 GB = 91 us at 12.9 TB/s of aggregate ingest, 144 us measured).  Eight
+//     column tiles share one panel: 0.70 GB.
+template <typename T, int NG, int WD, int AD, int KW, int CT>
+__global__ void __launch_bounds__(64 * CT * KW, (CT == 8 || KW == 2) ? 2 : 3)
 w4a16_gemm_m128_kernel(const GemmKParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Mfma<T>::frag frag_t;
   constexpr int MT = 4;
-  constexpr int NT = 256 * KW;     // threads
-  constexpr int AI = 4 / KW;       // 16-B activation items per thread and chunk
+  static_assert((CT == 4 || CT == 8) && CT * KW <= 8, "workgroups of 256 or 512 threads");
+  constexpr int NT = 64 * CT * KW; // threads
+  constexpr int AI = 1024 / NT;    // 16-B activation items per thread and chunk
   constexpr int JW = 4 / KW;       // k-steps (weight words) per wave and chunk
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ct = wave & 3;         // column tile of the workgroup
-  const int kw = wave >> 2;        // k part of the chunk (0 when KW == 1)
+  const int ct = wave & (CT - 1);  // column tile of the workgroup
+  const int kw = wave / CT;        // k part of the chunk (0 when KW == 1)
   const int nb = (int)(blockIdx.x % (unsigned)p.n_nblocks);
   const int ks = (int)(blockIdx.x / (unsigned)p.n_nblocks);
   // split-K ranges are planned in 128-deep units (W4_KC); this loop walks 64-deep chunks
@@ -78,7 +85,7 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
   const int clast = 2 * p.n_chunks - 1;
 
   const int n_tiles = (int)(p.N / 32);
-  const int gt = nb * 4 + ct;
+  const int gt = nb * CT + ct;
   const bool nvalid = gt < n_tiles;
   const int ntile = nvalid ? gt : n_tiles - 1;  // (clamped: computes on the last valid tile, no store)
 
@@ -285,12 +292,12 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
   }
 }
 
-template <typename T, int KW>
+template <typename T, int KW, int CT>
 static void launch_m128_t(const GemmKParams& kp, int ng, int wd, int n_blocks, hipStream_t st) {
-  const dim3 grid((unsigned)n_blocks), blk(256 * KW);
+  const dim3 grid((unsigned)n_blocks), blk(64 * CT * KW);
   const size_t lds = 2 * M128_BUF;
 #define SLM_M128(NGG, WDD) \
-  hipLaunchKernelGGL((w4a16_gemm_m128_kernel<T, NGG, WDD, 1, KW>), grid, blk, lds, st, kp)
+  hipLaunchKernelGGL((w4a16_gemm_m128_kernel<T, NGG, WDD, 1, KW, CT>), grid, blk, lds, st, kp)
   if (ng == 2) { if (wd == 4) SLM_M128(2, 4); else SLM_M128(2, 2); }
   else { if (wd == 4) SLM_M128(1, 4); else SLM_M128(1, 2); }
 #undef SLM_M128
@@ -300,12 +307,17 @@ static void launch_m128_t(const GemmKParams& kp, int ng, int wd, int n_blocks, h
 // kw = waves per column tile (1: 256-thread workgroups, 2: 512-thread workgroups with the chunk split in two)
 // (The activation look-ahead of two chunks, AD = 2, measured the same as one on every shape and is not built:
 //  profiles/r05_m128_70b_shapes.jsonl.)
-void launch_gemm_m128(const GemmKParams& kp, int dtype, int group_size, int wd, int kw, int n_blocks, hipStream_t st) {
+// ct = column tiles per workgroup (4 / 8; 8 only with kw = 1); n_blocks counts workgroups of ct tiles
+void launch_gemm_m128(const GemmKParams& kp, int dtype, int group_size, int wd, int kw, int ct, int n_blocks, hipStream_t st) {
   const int ng = group_size == 32 ? 2 : 1;
   if (dtype == SLM_BF16) {
-    if (kw == 2) launch_m128_t<bf16_tag, 2>(kp, ng, wd, n_blocks, st); else launch_m128_t<bf16_tag, 1>(kp, ng, wd, n_blocks, st);
+    if (ct == 8) launch_m128_t<bf16_tag, 1, 8>(kp, ng, wd, n_blocks, st);
+    else if (kw == 2) launch_m128_t<bf16_tag, 2, 4>(kp, ng, wd, n_blocks, st);
+    else launch_m128_t<bf16_tag, 1, 4>(kp, ng, wd, n_blocks, st);
   } else {
-    if (kw == 2) launch_m128_t<f16_tag, 2>(kp, ng, wd, n_blocks, st); else launch_m128_t<f16_tag, 1>(kp, ng, wd, n_blocks, st);
+    if (ct == 8) launch_m128_t<f16_tag, 1, 8>(kp, ng, wd, n_blocks, st);
+    else if (kw == 2) launch_m128_t<f16_tag, 2, 4>(kp, ng, wd, n_blocks, st);
+    else launch_m128_t<f16_tag, 1, 4>(kp, ng, wd, n_blocks, st);
   }
 }
 
