@@ -73,11 +73,29 @@ typedef __attribute__((address_space(3))) tr_v4s tr_lds_v4s;
 // half the barriers, table lookups and loop overhead per KV row -- in a DOUBLE-BUFFERED LDS image: the
 // next tile's registers are stored into the other buffer right after this tile's MFMAs, ONE barrier per
 // tile (the single-buffer form needs "everybody done reading" + "everybody done writing").
-template <typename T, int HD, int NW, bool PF, bool PLAIN, int KVT = 32, bool DB = false>
+// DMA (round 5, the double-buffered classes): the next tile travels HBM -> LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds) instead of through 32 staging VGPRs + ds_write.  Measured on the
+// register-staged form (tools/probes/experiments/attn_tile_pipe_halfsteps_and_lds_ahead.md): with the
+// staging taken out of the loop the kernel runs 19...29 % faster -- global-load issue, per-lane 64-bit
+// address arithmetic, eight 16-B LDS stores per thread and their waits are what the tile costs beside its
+// MFMAs.  Here:
+//   * the cache is addressed as a STRUCTURED buffer: index = cache slot (the block-table gather, bit-exact
+//     with sm80_kernel_mha.cuh:146-152), stride = the slot stride in the descriptor, per-lane offset = the
+//     16-B column -- the address multiply-add happens in the buffer unit, no 64-bit VALU;
+//   * a wave instruction writes 1 KiB of LDS linearly (lane l -> base + 16 l), so the LDS image is made
+//     on the SOURCE side: for K, lane l of instruction i fetches row 4i + l/16 (head_dim 128), column
+//     (l % 16) ^ (row % 16) -- the XOR swizzle of the image; for V, instruction (half h, sub-tile s)
+//     fetches row 32h + l/2, column 2s + l%2 -- exactly one [32 kv][16 d] sub-tile of the transpose-read
+//     image;
+//   * the cache slots of a tile's 64 rows are looked up ONCE per workgroup (64 threads, one row each, two
+//     tiles ahead) and handed round through LDS, instead of by every thread for its own rows.
+// Needs slot strides < 16 KiB (the descriptor's 14-bit stride field); the launcher falls back otherwise.
+template <typename T, int HD, int NW, bool PF, bool PLAIN, int KVT = 32, bool DB = false, bool DMA = false>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) attn_tile_kernel(const AttnKParams p, int tiles_per_seq) {
   typedef typename TileMfma<T>::frag frag_t;
   static_assert(KVT == 32 || KVT == 64, "KV tile rows");
   static_assert(!DB || PF, "the double-buffered form prefetches through registers");
+  static_assert(!DMA || DB, "LDS-DMA staging is built on the double-buffered form");
   constexpr int TILE_KV = KVT;
   constexpr int NH = KVT / 32;        // 32-row S^T blocks per tile
   constexpr int KSTEPS = HD / 16;     // MFMA k-steps of the QK product
@@ -195,7 +213,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
   const char* vbase = reinterpret_cast<const char*>(p.vc) + 2 * (int64_t)kvh * p.v_hs;
   const uint32_t k_sb = (uint32_t)(2 * p.k_ss), v_sb = (uint32_t)(2 * p.v_ss);
 
-  u32x4 kreg[ITEMS], vreg[ITEMS];
+  u32x4 kreg[DMA ? 1 : ITEMS], vreg[DMA ? 1 : ITEMS];
   // AHEAD: the block-table lookups (a global load the K/V addresses depend on) run one tile ahead
   // of the K/V loads that use them: prefill 423 -> 447 TFLOP/s, chunked 678 -> 731.  The one-wave
   // (verify) form is at its 256-VGPR cap and spills with the 8 extra registers (335 -> 401 us), so
@@ -218,10 +236,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
       __syncthreads();
     }
   }
-  int sreg[ITEMS];  // cache slots of the next tile_load
+  int sreg[DMA ? 1 : ITEMS];  // cache slots of the next tile_load
   auto slot_load = [&](int kt0) {
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
+    for (int i = 0; i < (DMA ? 0 : ITEMS); ++i) {
       const int r = (tid + nthreads * i) / NSLOT;
       // clamp: masked below, must stay in bounds (and inside the staged window)
       const int row = min(kt0 + r, min(wg_hi_s, kv_len) - 1);
@@ -234,7 +252,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
   // table lookup (a dependent global load) is off the critical path of the NEXT tile's K/V loads
   auto tile_load = [&](int kt_next) {
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
+    for (int i = 0; i < (DMA ? 0 : ITEMS); ++i) {
       const int sl = (tid + nthreads * i) % NSLOT;
       const int slot = sreg[i];
       const u32x4* kp_ = reinterpret_cast<const u32x4*>(kbase + (uint64_t)(uint32_t)slot * k_sb + 16 * sl);
@@ -254,7 +272,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
   };
   auto tile_store = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < ITEMS; ++i) {
+    for (int i = 0; i < (DMA ? 0 : ITEMS); ++i) {
       const int idx = tid + nthreads * i;
       const int r = idx / NSLOT, sl = idx % NSLOT;
       *reinterpret_cast<u32x4*>(k_lds + buf * K_BYTES + r * (HD * 2) + ((sl ^ (r & (NSLOT - 1))) << 4)) = kreg[i];
@@ -269,7 +287,87 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
                           (uint32_t)(((lane & 15) >> 2) * 32 + (lane & 3) * 8 + hh * 128 +
                                      ((lane >> 4) & 1) * (v_sub_base(1) - v_sub_base(0)));
 
-  if constexpr (PF) {
+  // ---- LDS-DMA staging (DMA) ----
+  typedef __attribute__((address_space(3))) void lds_void;
+  constexpr int ROWS_KI = 64 / NSLOT;                 // K rows one wave instruction (64 lanes x 16 B) covers
+  constexpr int KI = DMA ? (TILE_KV / ROWS_KI) / NW : 1;   // K instructions per wave and tile
+  constexpr int NSUB = HD / 16;                       // V sub-tiles per 32-row half
+  constexpr int VI = DMA ? (NH * NSUB) / NW : 1;      // V instructions per wave and tile
+  static_assert(!DMA || ((TILE_KV / ROWS_KI) % NW == 0 && (NH * NSUB) % NW == 0), "whole instructions per wave");
+  __shared__ int slot_lds[DMA ? 2 * TILE_KV : 1];     // cache slots of the rows of two tiles
+  // (the DMA is issued as inline asm, invisible to the compiler's waitcnt bookkeeping: through the builtin
+  //  hipcc makes every ds_read of k_lds / v_lds wait for the wave's own outstanding DMA into the OTHER
+  //  buffer -- it cannot tell the halves of one LDS array apart -- which serialises copy and compute; the
+  //  one wait the data needs is the explicit vmcnt(0) in front of the tile's barrier)
+  u32x4 k_rs = {0u, 0u, 0u, 0u}, v_rs = {0u, 0u, 0u, 0u};
+  int k_row[KI], v_row[VI];
+  int k_voff[KI], v_voff[VI];
+  const uint32_t k_lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)k_lds;
+  const uint32_t v_lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)v_lds;
+  if constexpr (DMA) {
+    // structured buffer descriptors: base, stride (14 bits), records, raw 32-bit data format
+    const uint64_t kb64 = (uint64_t)(uintptr_t)kbase, vb64 = (uint64_t)(uintptr_t)vbase;
+    k_rs = u32x4{(uint32_t)kb64, (uint32_t)((kb64 >> 32) & 0xffffu) | (k_sb << 16), 0x7fffffffu, 0x00020000u};
+    v_rs = u32x4{(uint32_t)vb64, (uint32_t)((vb64 >> 32) & 0xffffu) | (v_sb << 16), 0x7fffffffu, 0x00020000u};
+#pragma unroll
+    for (int j = 0; j < KI; ++j) {
+      k_row[j] = ROWS_KI * (wave * KI + j) + lane / NSLOT;
+      k_voff[j] = 16 * ((lane % NSLOT) ^ (k_row[j] & (NSLOT - 1)));
+    }
+#pragma unroll
+    for (int j = 0; j < VI; ++j) {
+      const int ii = wave * VI + j;
+      v_row[j] = 32 * (ii / NSUB) + (lane >> 1);
+      v_voff[j] = 16 * (2 * (ii % NSUB) + (lane & 1));
+    }
+  }
+  auto dma16 = [&](const u32x4& rs, uint32_t dst, int vindex, int voff) {
+    const u32x2 iv = {(uint32_t)vindex, (uint32_t)voff};
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 idxen offen lds"
+                 :
+                 : "v"(iv), "s"(rs), "s"(dst)
+                 : "memory");
+  };
+  // tile whose slots sit in slot_lds[sb] -> LDS buffer `buf`
+  auto dma_tile = [&](int buf, int sb) {
+    if constexpr (DMA) {
+      int ks[KI], vs[VI];
+#pragma unroll
+      for (int j = 0; j < KI; ++j) ks[j] = slot_lds[sb * TILE_KV + k_row[j]];
+#pragma unroll
+      for (int j = 0; j < VI; ++j) vs[j] = slot_lds[sb * TILE_KV + v_row[j]];
+#pragma unroll
+      for (int j = 0; j < KI; ++j) dma16(k_rs, k_lds0 + buf * K_BYTES + (wave * KI + j) * 1024, ks[j], k_voff[j]);
+#pragma unroll
+      for (int j = 0; j < VI; ++j) {
+        const int ii = wave * VI + j;
+        dma16(v_rs, v_lds0 + buf * V_BYTES + (ii / NSUB) * VH_BYTES + v_sub_base(ii % NSUB), vs[j], v_voff[j]);
+      }
+    }
+  };
+  // one row per thread (threads 0..63): the slot of row kt0 + tid (clamped: masked below, in bounds)
+  auto slot_lookup = [&](int kt0) -> int {
+    const int row = min(kt0 + (tid & (TILE_KV - 1)), min(wg_hi_s, kv_len) - 1);
+    return p.bt[bcu0 + (row >> p.block_shift)] + (row & p.block_mask);
+  };
+
+  if constexpr (DMA) {
+    if (wg_lo < wg_hi_s) {
+      if (tid < TILE_KV) {
+        slot_lds[tid] = slot_lookup(wg_lo);
+        slot_lds[TILE_KV + tid] = slot_lookup(wg_lo + TILE_KV);
+      }
+      __syncthreads();
+      dma_tile(0, 0);
+    }
+    // the Q fragments are consumed HERE as far as the compiler is concerned: otherwise its wait for them sits
+    // in front of the first MFMA inside the loop, counted against its own loads only -- and drains the DMA
+    // issued in front of it on every iteration
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) asm volatile("" ::"v"(qf[s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else if constexpr (PF) {
     if (wg_lo < wg_hi_s) {
       slot_load(wg_lo);
       tile_load(min(wg_lo + TILE_KV, wg_hi_s - 1));
@@ -278,8 +376,16 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
     __syncthreads();
   }
   int cur = 0;  // LDS buffer holding the tile being consumed (DB)
+  int tpar = 0; // parity of the tile being consumed (DMA: slot_lds[tpar ^ 1] holds the next tile's slots)
   for (int kt0 = wg_lo; kt0 < wg_hi_s; kt0 += TILE_KV) {
-    if constexpr (PF) {
+    int slot_next = 0;
+    if constexpr (DMA) {
+      // next tile HBM -> the other LDS buffer (free since the last barrier), the tile after that: its slots
+      // (the lookup is issued by every thread, in FRONT of the DMA: a compiler-tracked load behind the
+      //  untracked DMA would make the first wait on it drain the whole copy)
+      slot_next = slot_lookup(kt0 + 2 * TILE_KV);
+      dma_tile(cur ^ 1, tpar ^ 1);
+    } else if constexpr (PF) {
       // next tile's rows travel HBM -> registers while this tile is consumed from LDS
       if constexpr (!AHEAD) slot_load(min(kt0 + TILE_KV, wg_hi_s - 1));
       tile_load(min(kt0 + 2 * TILE_KV, wg_hi_s - 1));
@@ -423,7 +529,14 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
         oacc[d] = TileMfma<T>::run(__builtin_bit_cast(frag_t, va), pfrag, oacc[d]);
       }
     }
-    if constexpr (DB) {
+    if constexpr (DMA) {
+      // slot_lds[tpar] held this tile's slots (read when its DMA was issued, one barrier ago)
+      if (tid < TILE_KV) slot_lds[tpar * TILE_KV + tid] = slot_next;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile has landed
+      __syncthreads();
+      cur ^= 1;
+      tpar ^= 1;
+    } else if constexpr (DB) {
       // the other buffer was last read one tile ago and every wave has passed the barrier since:
       // store the prefetched tile there right away; ONE barrier publishes it and retires this tile
       tile_store(cur ^ 1);
@@ -487,6 +600,9 @@ int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t rows, hipStream_t
   const int pf_mode = tune_get(TUNE_ATTN_TILE_PF, 1);
   const bool pf = pf_mode != 0;
   const bool plain = kp.softcap <= 0.f && kp.alibi == nullptr && kp.window < 0;
+  // LDS-DMA staging of the 64-row classes: the slot strides must fit the buffer descriptor's 14-bit stride
+  // field (SLM_ATTN_TILE_PF = 4 keeps the register-staged form for A/B runs)
+  const bool dma = pf_mode != 4 && 2 * kp.k_ss < 16384 && 2 * kp.v_ss < 16384 && 2 * kp.k_ss > 0 && 2 * kp.v_ss > 0;
 #define SLM_TILE(TT, HDD, NWW)                                                                    \
   do {                                                                                            \
     if (pf && plain) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
@@ -497,7 +613,9 @@ int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t rows, hipStream_t
   // 32-row single-buffer form for A/B runs)
 #define SLM_TILE64(TT, HDD, NWW)                                                                  \
   do {                                                                                            \
-    if (plain) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, true, 64, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
+    if (plain && dma) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, true, 64, true, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
+    else if (dma) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, false, 64, true, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
+    else if (plain) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, true, 64, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
     else hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, false, 64, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
   } while (0)
   // 64-row tiles where the instantiation keeps two waves per SIMD (no AGPR overflow): head_dim 128 with 4
@@ -507,14 +625,14 @@ int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t rows, hipStream_t
   do {                                                                                            \
     if (nw == 1) SLM_TILE(TT, 128, 1);                                                            \
     else if (nw == 2) SLM_TILE(TT, 128, 2);                                                       \
-    else if (pf_mode == 1) SLM_TILE64(TT, 128, 4);                                                \
+    else if (pf_mode == 1 || pf_mode == 4) SLM_TILE64(TT, 128, 4);                                                \
     else SLM_TILE(TT, 128, 4);                                                                    \
   } while (0)
 #define SLM_TILE_NW64(TT)                                                                         \
   do {                                                                                            \
     if (nw == 1) SLM_TILE(TT, 64, 1);                                                             \
-    else if (pf_mode == 1 && nw == 2) SLM_TILE64(TT, 64, 2);                                      \
-    else if (pf_mode == 1) SLM_TILE64(TT, 64, 4);                                                 \
+    else if ((pf_mode == 1 || pf_mode == 4) && nw == 2) SLM_TILE64(TT, 64, 2);                                      \
+    else if (pf_mode == 1 || pf_mode == 4) SLM_TILE64(TT, 64, 4);                                                 \
     else if (nw == 2) SLM_TILE(TT, 64, 2); else SLM_TILE(TT, 64, 4);                              \
   } while (0)
   if (dtype == SLM_BF16) {

@@ -140,6 +140,52 @@ def test_llama_prefill_then_decode_logits_match_oracle(name):
     assert agree >= 0.9 * total, f"{name}: greedy ids agree on only {agree}/{total} rows"
 
 
+@pytest.mark.parametrize("host", ["py", "cpp"])
+def test_llama_two_lane_decode_step_and_cpp_host_match_oracle(host):
+    """Round 5 (round-4 review, parity hole): the TWO-LANE decode step and the C++ host step
+    (slm::LlamaForCausalLMHip) were pinned to the oracle only transitively (bit-identical to their half batches /
+    to the Python mirror).  Here both are compared with the oracle-composed fp32 forward and its bf16-storage
+    twin directly: 72 sequences (>= 64: two lanes of 64 + 8 rows on two streams), prefill in one step, then
+    three pure-decode steps, same bounds as the one-lane cases above."""
+    from scalellm_amd.decode import LlamaDecodeStep, LlamaShape
+    shape, quant, gs = LlamaShape.tiny(), "awq", 128
+    prompt_lens = [3 + (5 * i) % 17 for i in range(72)]
+    B, n_decode = 16, 3
+    seqs = Sequences(prompt_lens, n_decode + 1, B, shape.vocab, seed=11)
+    model = LlamaDecodeStep(shape, sum(prompt_lens) + 8, seqs.n_blocks, B, quant_method=quant, group_size=gs,
+                            dtype=torch.bfloat16, device=DEV, seed=5, keep_checkpoint=True)
+    model.lanes_min = 64   # (the automatic rule wants 12 MiB of K + V per sequence: tests/test_host_logic_cpu.py)
+    model.reserve_workspaces(sum(prompt_lens) + 8, 64)
+    runner = model
+    if host == "cpp":
+        from scalellm_amd import cpp_host
+        cpp_host.load_shim()
+        runner = cpp_host.from_decode_step(model, B, sum(prompt_lens) + 8, fused=True, lanes=64)
+    ref_model = _oracle_twin(model, quant, gs)
+    twin_model = _oracle_twin(model, quant, gs, storage="bf16")
+    steps = [list(prompt_lens)] + [[1] * len(prompt_lens)] * n_decode
+    agree = total = 0
+    for si, new_lens in enumerate(steps):
+        inp = seqs.inputs(new_lens)
+        tokens, positions, params = _params(inp)
+        if host == "cpp":
+            from scalellm_amd import cpp_host
+            logits = runner.decode_step(tokens, positions, cpp_host.cpp_params(params), return_logits=True)
+            lanes = runner.last_lanes()
+        else:
+            logits = model.forward(tokens, positions, params, return_logits=True)
+            lanes = model.last_lanes
+        torch.cuda.synchronize()
+        assert lanes == (2 if si > 0 else 1), (host, si, lanes)
+        got = logits.float().cpu().numpy()
+        a, n, _ = check_logits(got, ref_model.forward(inp), 3e-2, f"two lanes ({host}) step {si} vs fp32 oracle")
+        agree, total = agree + a, total + n
+        check_logits(got, twin_model.forward(inp), 1.5e-2, f"two lanes ({host}) step {si} vs bf16-storage twin")
+        seqs.advance(new_lens)
+        seqs.feed(inp, got.argmax(-1))
+    assert agree >= 0.9 * total, f"greedy ids agree on only {agree}/{total} rows"
+
+
 @pytest.mark.parametrize("wide", [False, True])
 def test_llama_one_layer_stage_by_stage_against_storage_twin(wide):
     """The tight pin behind the logits bounds: ONE decoder layer, prefill step, every buffer of the

@@ -11,6 +11,7 @@ from scalellm_amd import kernels  # noqa: E402
 from scalellm_amd.decode import _rand_int4_linear  # noqa: E402
 
 SHAPES = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 28672), "down": (14336, 4096)}
+SHAPES70 = {"qkv70": (8192, 10240), "o70": (8192, 8192), "gate_up70": (8192, 57344), "down70": (28672, 8192)}
 
 
 def main():
@@ -20,8 +21,8 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     kernels.reserve_workspace(1 << 30)
     only = os.environ.get("SHAPES", "")
-    for name, (K, N) in SHAPES.items():
-        if only and name not in only.split(","):
+    for name, (K, N) in {**SHAPES, **SHAPES70}.items():
+        if (only and name not in only.split(",")) or (not only and name in SHAPES70):
             continue
         ck = _rand_int4_linear(g, K, N, 128, "awq", torch.bfloat16, dev)
         packed = kernels.awq_repack(ck["qweight"], ck["qzeros"], ck["scales"], 128)
@@ -30,7 +31,7 @@ def main():
             c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
             torch.cuda.synchronize()
             # marker kernel so the trace can be segmented: fill with a recognisable size
-            torch.zeros(M * 1000 + {"qkv": 1, "o": 2, "gate_up": 3, "down": 4}[name], device=dev)
+            torch.zeros(M * 1000 + {"qkv": 1, "o": 2, "gate_up": 3, "down": 4}[name.replace("70", "")], device=dev)
             for _ in range(n):
                 kernels.gptq_gemm(x, packed, c)
             torch.cuda.synchronize()
