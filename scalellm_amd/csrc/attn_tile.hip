@@ -24,6 +24,8 @@
 //
 // K/V rows are gathered through the block table (slot = table[i >> log2 bs] + (i & (bs-1)),
 // bit-exact with sm80_kernel_mha.cuh:146-152) by all waves of the workgroup, 16 B per lane.
+#include <type_traits>
+
 #include "attn_common.h"
 #include "tuning.h"
 
@@ -90,12 +92,23 @@ typedef __attribute__((address_space(3))) tr_v4s tr_lds_v4s;
 //   * the cache slots of a tile's 64 rows are looked up ONCE per workgroup (64 threads, one row each, two
 //     tiles ahead) and handed round through LDS, instead of by every thread for its own rows.
 // Needs slot strides < 16 KiB (the descriptor's 14-bit stride field); the launcher falls back otherwise.
-template <typename T, int HD, int NW, bool PF, bool PLAIN, int KVT = 32, bool DB = false, bool DMA = false>
+// PIPE (round 5, on the DMA form): the wave is software-pipelined ACROSS tiles -- two score blocks live:
+//     A(t): S' = K[t+1] . Q^T  (16 MFMAs at head_dim 128)   ||   P = exp2(S * c - m), l += sum P   (tile t)
+//     B(t): O += V[t]^T . P    (16 MFMAs)                    ||   row max of S', lazy-rescale decision for t + 1
+// Unpipelined, a wave's tile is QK^T -> softmax -> P.V strictly in turn (each needs the previous result) and the
+// matrix pipe idles through the wave's whole softmax unless the co-resident wave happens to be in a matrix phase;
+// here the exponentials sit in the shadow of the NEXT tile's QK^T inside the same wave.  K runs one tile ahead
+// of V; with the copy issued at the START of an iteration (LDS-DMA, after the barrier) two K and two V buffers
+// still suffice: iteration t reads K[t+1] (buffer (t+1)&1) and V[t] (t&1) and fills K[t+2] -> t&1 (last read
+// by QK^T(t) in iteration t-1) and V[t+1] -> (t+1)&1 (last read by P.V(t-1)).  One barrier per 64 rows as before;
+// 32 more VGPRs (the second score block), which the DMA form freed.  Cross-half exchanges by v_permlane32_swap.
+template <typename T, int HD, int NW, bool PF, bool PLAIN, int KVT = 32, bool DB = false, bool DMA = false, bool PIPE = false>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) attn_tile_kernel(const AttnKParams p, int tiles_per_seq) {
   typedef typename TileMfma<T>::frag frag_t;
   static_assert(KVT == 32 || KVT == 64, "KV tile rows");
   static_assert(!DB || PF, "the double-buffered form prefetches through registers");
   static_assert(!DMA || DB, "LDS-DMA staging is built on the double-buffered form");
+  static_assert(!PIPE || (DMA && KVT == 64), "the pipelined form is built on the LDS-DMA form");
   constexpr int TILE_KV = KVT;
   constexpr int NH = KVT / 32;        // 32-row S^T blocks per tile
   constexpr int KSTEPS = HD / 16;     // MFMA k-steps of the QK product
@@ -294,7 +307,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
   constexpr int NSUB = HD / 16;                       // V sub-tiles per 32-row half
   constexpr int VI = DMA ? (NH * NSUB) / NW : 1;      // V instructions per wave and tile
   static_assert(!DMA || ((TILE_KV / ROWS_KI) % NW == 0 && (NH * NSUB) % NW == 0), "whole instructions per wave");
-  __shared__ int slot_lds[DMA ? 2 * TILE_KV : 1];     // cache slots of the rows of two tiles
+  __shared__ int slot_lds[PIPE ? 3 * TILE_KV : DMA ? 2 * TILE_KV : 1];   // cache slots of the rows of two (PIPE: three) tiles
   // (the DMA is issued as inline asm, invisible to the compiler's waitcnt bookkeeping: through the builtin
   //  hipcc makes every ds_read of k_lds / v_lds wait for the wave's own outstanding DMA into the OTHER
   //  buffer -- it cannot tell the halves of one LDS array apart -- which serialises copy and compute; the
@@ -328,16 +341,21 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
                  : "v"(iv), "s"(rs), "s"(dst)
                  : "memory");
   };
-  // tile whose slots sit in slot_lds[sb] -> LDS buffer `buf`
-  auto dma_tile = [&](int buf, int sb) {
+  // K / V rows of the tile whose slots sit in slot_lds[sb] -> LDS buffer `buf`
+  auto dma_k = [&](int buf, int sb) {
     if constexpr (DMA) {
-      int ks[KI], vs[VI];
+      int ks[KI];
 #pragma unroll
       for (int j = 0; j < KI; ++j) ks[j] = slot_lds[sb * TILE_KV + k_row[j]];
 #pragma unroll
-      for (int j = 0; j < VI; ++j) vs[j] = slot_lds[sb * TILE_KV + v_row[j]];
-#pragma unroll
       for (int j = 0; j < KI; ++j) dma16(k_rs, k_lds0 + buf * K_BYTES + (wave * KI + j) * 1024, ks[j], k_voff[j]);
+    }
+  };
+  auto dma_v = [&](int buf, int sb) {
+    if constexpr (DMA) {
+      int vs[VI];
+#pragma unroll
+      for (int j = 0; j < VI; ++j) vs[j] = slot_lds[sb * TILE_KV + v_row[j]];
 #pragma unroll
       for (int j = 0; j < VI; ++j) {
         const int ii = wave * VI + j;
@@ -345,12 +363,182 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
       }
     }
   };
+  auto dma_tile = [&](int buf, int sb) {
+    dma_k(buf, sb);
+    dma_v(buf, sb);
+  };
   // one row per thread (threads 0..63): the slot of row kt0 + tid (clamped: masked below, in bounds)
   auto slot_lookup = [&](int kt0) -> int {
     const int row = min(kt0 + (tid & (TILE_KV - 1)), min(wg_hi_s, kv_len) - 1);
     return p.bt[bcu0 + (row >> p.block_shift)] + (row & p.block_mask);
   };
 
+  if constexpr (PIPE) {
+    constexpr float LAZY_TH = 6.0f;
+    constexpr int SPS = 16 * NH / KSTEPS;   // scores exponentiated per k-step of the QK^T beside them (4 / 8)
+    static_assert(SPS == 4 || SPS == 8, "head_dim 128 / 64");
+    typedef std::integral_constant<int, 0> P0;
+    typedef std::integral_constant<int, 1> P1;
+    f32x16 sc[2][NH];             // two score blocks: the tile being exponentiated and the next tile's QK^T
+    float cm[2] = {1.0f, 1.0f};   // multiplier of a block's scores inside the exponent's fma (1 once a masked block was rewritten)
+    float l_lane = 0.f;           // this lane's share of the row sum (the lane halves meet once, at the end)
+    const int dmin = kv_len - q_len + (row0 + wave * 32) / G;   // smallest diagonal of the wave's rows
+    auto xhalf = [&](float x, bool take_max) {   // combine with the other lane half
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+      const float a = __uint_as_float(r[0]), b = __uint_as_float(r[1]);
+      return take_max ? fmaxf(a, b) : a + b;
+    };
+    auto qk_step = [&](auto pc, int kbuf, int s) {   // k-step s of sc[P] = K[kbuf] . Q^T
+      constexpr int P = decltype(pc)::value;
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const int kr = 32 * h + l31;
+        const u32x4 kv4 = *reinterpret_cast<const u32x4*>(k_lds + kbuf * K_BYTES + kr * (HD * 2) +
+                                                          (((2 * s + hh) ^ (kr & (NSLOT - 1))) << 4));
+        sc[P][h] = TileMfma<T>::run(__builtin_bit_cast(frag_t, kv4), qf[s], sc[P][h]);
+      }
+    };
+    auto zero = [&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[P][h][r] = 0.f;
+    };
+    // scale / soft-cap / alibi / mask of block P (tile at kt0), its row max, lazy rescale of O and l
+    auto decide = [&](auto pc, int kt0) {
+      constexpr int P = decltype(pc)::value;
+      const bool interior = PLAIN && p.scale_log2 > 0.f && kt0 + TILE_KV <= kv_len && kt0 + TILE_KV - 1 <= dmin;
+      float mloc = -INFINITY;
+      if (interior) {
+#pragma unroll
+        for (int r = 0; r < 16 * NH; r += 2) mloc = fmaxf(fmaxf(mloc, sc[P][r >> 4][r & 15]), sc[P][(r + 1) >> 4][(r + 1) & 15]);
+        mloc *= p.scale_log2;
+        cm[P] = p.scale_log2;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16 * NH; ++r) {
+          const int kv_idx = kt0 + 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * hh;
+          float a = sc[P][r >> 4][r & 15];
+          if constexpr (!PLAIN) {
+            if (p.softcap > 0.f) a = fast_tanh(a * p.pre_scale);
+            a = a * p.scale_log2 + slope2 * (float)kv_idx;
+          } else {
+            a = a * p.scale_log2;
+          }
+          bool vis = jvalid && kv_idx <= diag && kv_idx < kv_len;
+          if constexpr (!PLAIN) {
+            if (p.window >= 0) vis = vis && (diag - kv_idx) <= p.window;
+          }
+          a = vis ? a : -INFINITY;
+          sc[P][r >> 4][r & 15] = a;
+          mloc = fmaxf(mloc, a);
+        }
+        cm[P] = 1.0f;
+      }
+      mloc = xhalf(mloc, true);
+      // (every P.V issued so far has been issued in front of this point: O is complete up to the previous tile)
+      if (__any(mloc > m_run + LAZY_TH)) {
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = fast_exp2(m_run - m_new);
+        m_run = m_new;
+        l_lane *= alpha;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+      }
+    };
+    // A: [QK^T of the next tile -> sc[1 - P]]  ||  exponentials of sc[P], packed as the B fragments of P.V
+    auto step_a = [&](auto pc, auto with_qk, int kbuf_next, u32x4 (&pb)[2 * NH]) {
+      constexpr int P = decltype(pc)::value;
+      constexpr bool QK = decltype(with_qk)::value;
+      if constexpr (QK) zero(std::integral_constant<int, 1 - P>{});
+      const float c = cm[P];
+      float sv[8];
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) {
+        if constexpr (QK) qk_step(std::integral_constant<int, 1 - P>{}, kbuf_next, s);
+#pragma unroll
+        for (int e = 0; e < SPS; ++e) {
+          const int r = SPS * s + e;
+          const float v = fast_exp2(fmaf(sc[P][r >> 4][r & 15], c, -m_run));
+          sv[r & 7] = v;
+          l_lane += v;
+        }
+        if (((s + 1) * SPS) % 8 == 0) {
+          const int g = (s + 1) * SPS / 8 - 1;
+          pb[g].x = pack2<T>(sv[0], sv[1]);
+          pb[g].y = pack2<T>(sv[2], sv[3]);
+          pb[g].z = pack2<T>(sv[4], sv[5]);
+          pb[g].w = pack2<T>(sv[6], sv[7]);
+        }
+      }
+    };
+    // B: O^T += V[vbuf]^T . P^T
+    auto step_b = [&](int vbuf, const u32x4 (&pb)[2 * NH]) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2 * NH; ++s2) {
+        const frag_t pfrag = __builtin_bit_cast(frag_t, pb[s2]);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+          const uintptr_t va0 = v_lane + (uint32_t)(v_sub_base(2 * d) + (16 * (s2 & 1)) * 32 + (s2 >> 1) * VH_BYTES + vbuf * V_BYTES);
+          const tr_v4s t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds_v4s*)va0);
+          const tr_v4s t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds_v4s*)(va0 + 8 * 32));
+          const u32x2 v0 = __builtin_bit_cast(u32x2, t0), v1 = __builtin_bit_cast(u32x2, t1);
+          const u32x4 va = {v0.x, v0.y, v1.x, v1.y};
+          oacc[d] = TileMfma<T>::run(__builtin_bit_cast(frag_t, va), pfrag, oacc[d]);
+        }
+      }
+    };
+    if (wg_lo < wg_hi_s) {
+      const int nt = (wg_hi_s - wg_lo + TILE_KV - 1) / TILE_KV;
+      if (tid < TILE_KV) {
+        slot_lds[tid] = slot_lookup(wg_lo);
+        slot_lds[TILE_KV + tid] = slot_lookup(wg_lo + TILE_KV);
+        slot_lds[2 * TILE_KV + tid] = slot_lookup(wg_lo + 2 * TILE_KV);
+      }
+      __syncthreads();
+      dma_tile(0, 0);
+      dma_k(1, 1);
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) asm volatile("" ::"v"(qf[s]));   // (Q is waited for here, not in the loop: see DMA)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      zero(P0{});
+#pragma unroll
+      for (int s = 0; s < KSTEPS; ++s) qk_step(P0{}, 0, s);
+      decide(P0{}, wg_lo);
+      __syncthreads();   // K buffer 0 is refilled at the top of the first iteration: every wave is done with it
+      int m3 = 0;        // t mod 3
+      // tile t: its scores in sc[P]
+      auto body = [&](auto pc, int t) {
+        constexpr int P = decltype(pc)::value;
+        const int kt0 = wg_lo + t * TILE_KV;
+        const bool more = t + 1 < nt;
+        // wave 0 looks up the slots of tile t + 3 (one row per lane), in FRONT of the DMA: see DMA
+        int slot_next = 0;
+        if (wave == 0) slot_next = slot_lookup(kt0 + 3 * TILE_KV);
+        const int m3p1 = m3 == 2 ? 0 : m3 + 1, m3p2 = m3 == 0 ? 2 : m3 - 1;
+        dma_k(t & 1, m3p2);          // K[t+2]
+        dma_v((t + 1) & 1, m3p1);    // V[t+1]
+        u32x4 pb[2 * NH];
+        if (more) step_a(pc, std::true_type{}, (t + 1) & 1, pb);
+        else step_a(pc, std::false_type{}, 0, pb);
+        step_b(t & 1, pb);
+        if (more) decide(std::integral_constant<int, 1 - P>{}, kt0 + TILE_KV);
+        if (wave == 0) slot_lds[m3 * TILE_KV + lane] = slot_next;   // tile t + 3 takes tile t's place in the ring
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        m3 = m3p1;
+      };
+      for (int t = 0; t < nt; t += 2) {
+        body(P0{}, t);
+        if (t + 1 < nt) body(P1{}, t + 1);
+      }
+    }
+    l_run = xhalf(l_lane, false);
+  } else {
   if constexpr (DMA) {
     if (wg_lo < wg_hi_s) {
       if (tid < TILE_KV) {
@@ -381,9 +569,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
     int slot_next = 0;
     if constexpr (DMA) {
       // next tile HBM -> the other LDS buffer (free since the last barrier), the tile after that: its slots
-      // (the lookup is issued by every thread, in FRONT of the DMA: a compiler-tracked load behind the
-      //  untracked DMA would make the first wait on it drain the whole copy)
-      slot_next = slot_lookup(kt0 + 2 * TILE_KV);
+      // (the lookup -- wave 0, one row per lane, a wave-uniform branch -- is issued in FRONT of the DMA: a
+      //  compiler-tracked load behind the untracked DMA would make the first wait on it drain the whole copy;
+      //  its one consumer is the store at the bottom of the iteration, where everything is drained anyway)
+      if (wave == 0) slot_next = slot_lookup(kt0 + 2 * TILE_KV);
       dma_tile(cur ^ 1, tpar ^ 1);
     } else if constexpr (PF) {
       // next tile's rows travel HBM -> registers while this tile is consumed from LDS
@@ -531,7 +720,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
     }
     if constexpr (DMA) {
       // slot_lds[tpar] held this tile's slots (read when its DMA was issued, one barrier ago)
-      if (tid < TILE_KV) slot_lds[tpar * TILE_KV + tid] = slot_next;
+      if (wave == 0) slot_lds[tpar * TILE_KV + lane] = slot_next;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next tile has landed
       __syncthreads();
       cur ^= 1;
@@ -548,6 +737,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
       __syncthreads();
     }
   }
+  }  // !PIPE
 
   // ---- epilogue: O^T[d][q] / l -> out[token][head][d]; 4 consecutive d per register quad ----
   if (!jvalid) return;
@@ -602,6 +792,9 @@ int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t rows, hipStream_t
   const bool plain = kp.softcap <= 0.f && kp.alibi == nullptr && kp.window < 0;
   // LDS-DMA staging of the 64-row classes: the slot strides must fit the buffer descriptor's 14-bit stride
   // field (SLM_ATTN_TILE_PF = 4 keeps the register-staged form for A/B runs)
+  // the cross-tile pipeline: the instantiations without soft-cap / alibi / window (with them the head_dim-128 form
+  // spills 22...31 VGPRs at its 256-register cap); SLM_ATTN_TILE_PF = 5: LDS-DMA staging without it
+  const bool pipe = pf_mode != 5;
   const bool dma = pf_mode != 4 && 2 * kp.k_ss < 16384 && 2 * kp.v_ss < 16384 && 2 * kp.k_ss > 0 && 2 * kp.v_ss > 0;
 #define SLM_TILE(TT, HDD, NWW)                                                                    \
   do {                                                                                            \
@@ -613,7 +806,8 @@ int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t rows, hipStream_t
   // 32-row single-buffer form for A/B runs)
 #define SLM_TILE64(TT, HDD, NWW)                                                                  \
   do {                                                                                            \
-    if (plain && dma) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, true, 64, true, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
+    if (plain && dma && pipe) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, true, 64, true, true, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
+    else if (plain && dma) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, true, 64, true, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
     else if (dma) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, false, 64, true, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
     else if (plain) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, true, 64, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
     else hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, false, 64, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
@@ -625,14 +819,14 @@ int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t rows, hipStream_t
   do {                                                                                            \
     if (nw == 1) SLM_TILE(TT, 128, 1);                                                            \
     else if (nw == 2) SLM_TILE(TT, 128, 2);                                                       \
-    else if (pf_mode == 1 || pf_mode == 4) SLM_TILE64(TT, 128, 4);                                                \
+    else if (pf_mode == 1 || pf_mode == 4 || pf_mode == 5) SLM_TILE64(TT, 128, 4);                                                \
     else SLM_TILE(TT, 128, 4);                                                                    \
   } while (0)
 #define SLM_TILE_NW64(TT)                                                                         \
   do {                                                                                            \
     if (nw == 1) SLM_TILE(TT, 64, 1);                                                             \
-    else if ((pf_mode == 1 || pf_mode == 4) && nw == 2) SLM_TILE64(TT, 64, 2);                                      \
-    else if (pf_mode == 1 || pf_mode == 4) SLM_TILE64(TT, 64, 4);                                                 \
+    else if ((pf_mode == 1 || pf_mode == 4 || pf_mode == 5) && nw == 2) SLM_TILE64(TT, 64, 2);                                      \
+    else if (pf_mode == 1 || pf_mode == 4 || pf_mode == 5) SLM_TILE64(TT, 64, 4);                                                 \
     else if (nw == 2) SLM_TILE(TT, 64, 2); else SLM_TILE(TT, 64, 4);                              \
   } while (0)
   if (dtype == SLM_BF16) {
