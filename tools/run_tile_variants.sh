@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of attn_tile.hip build variants (tools/build_tile_variant.sh): bench_prefill under each lib
+# A/B of attn_tile.hip build variants (tools/build_variant.sh): bench_prefill under each lib
 # usage: run_tile_variants.sh <outdir> <variant> [<variant> ...]   ("base" = the shipped lib)
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/$1; shift; mkdir -p $O
