@@ -517,7 +517,7 @@ constexpr bool w4_pre_fits(int /*mt*/, int ntw, int ng, int pc) { return !(ntw =
 struct GemmPlan {
   int mt, ntw, ng, pc, post, small, gemv, split_k, chunks_per_split, n_mblocks, n_nblocks;
   int ks, ks_cw, ks_nw, ks_tpw, ks_mt;  // K-sliced small-M kernel (w4_ks.hip)
-  int m128, m128_wd, m128_kw, m128_ct;  // 65 <= M <= 128 kernel (w4_m128.hip)
+  int m128, m128_wd, m128_kw, m128_ct, m128_adma;  // 65 <= M <= 128 kernel (w4_m128.hip)
   size_t lds_bytes, part_bytes, aperm_bytes;
 };
 
@@ -729,6 +729,7 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   pl->m128_wd = 2;
   pl->m128_kw = 1;
   pl->m128_ct = 4;
+  pl->m128_adma = 0;
   // Where (measured, profiles/r05_m128_*.jsonl): deep-K layers (K >= 8192: the Llama-3-70B shapes, where the
   // general kernel already took its ~200-VGPR BM = 128 tiles) -- the 70B step 50.6 -> 49.4 ms.  On the
   // Llama-3-8B shapes (K = 4096, and 14336 x 4096) it ties the BM = 64 general kernel alone and in the two-lane
@@ -775,6 +776,8 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
     pl->m128_kw = kw_knob == 2 || (kw_knob != 1 && (int64_t)pl->n_nblocks * pl->split_k <= 512) ? 2 : 1;
     pl->m128_ct = ct;
     if (ct == 8) pl->m128_kw = 1;
+    // activations by LDS-DMA (256-column form): 70B layer at M = 128 284.6 -> 271.1 us (profiles/r05_m128_adma.jsonl)
+    pl->m128_adma = ct == 8 && tune_get(TUNE_W4_M128_ADMA, 1) != 0;
     pl->lds_bytes = W4_M128_LDS_BYTES;
   }
   pl->part_bytes = pl->split_k > 1 ? (size_t)pl->split_k * a->M * a->N * sizeof(float) : 0;
@@ -1003,7 +1006,7 @@ static int gemm_impl(const slm_w4_gemm_args* a, const slm_w4_norm_prologue* np, 
   else if (pl.small)
     launch_gemm_small(kp, a->dtype, pl.ng, pl.n_nblocks * pl.n_mblocks * pl.split_k, st);
   else if (pl.m128)
-    launch_gemm_m128(kp, a->dtype, (int)a->group_size, pl.m128_wd, pl.m128_kw, pl.m128_ct, pl.n_nblocks * pl.split_k, st);
+    launch_gemm_m128(kp, a->dtype, (int)a->group_size, pl.m128_wd, pl.m128_kw, pl.m128_ct, pl.m128_adma, pl.n_nblocks * pl.split_k, st);
   else if (pl.mt == 16)
     launch_gemm_xl(kp, a->dtype, pl.ng, pl.n_nblocks * pl.n_mblocks * pl.split_k, st);
   else if (pl.mt == 8)

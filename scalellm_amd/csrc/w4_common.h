@@ -269,7 +269,7 @@ constexpr size_t w4_ks_lds_bytes(int nw) { return (size_t)4 * nw * 4096 + 64; } 
 
 // 65 <= M <= 128: all rows in one workgroup, 64-deep chunks, two workgroups per CU next to the decode
 // attention stream (w4_m128.hip, round 5); wd = weight ring depth, (64-deep chunks per split) % wd == 0
-void launch_gemm_m128(const GemmKParams& kp, int dtype, int group_size, int wd, int kw, int ct, int n_blocks, hipStream_t st);
+void launch_gemm_m128(const GemmKParams& kp, int dtype, int group_size, int wd, int kw, int ct, int adma, int n_blocks, hipStream_t st);
 constexpr size_t W4_M128_LDS_BYTES = 2 * 128 * 128;
 
 // warp-specialised large-M kernel (w4_ws.hip): BM = 256, BN = 128, 512 threads

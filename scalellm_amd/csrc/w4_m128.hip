@@ -60,7 +60,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t m128_rsrc(const void* base, ui
 //     (~21 B/clk per CU) -- not HBM, not the matrix pipe -- is what a 70B-sized layer waits for (gate_up:
 //     448 workgroups x 2.5 MB = 1.17 GB = 91 us at 12.9 TB/s of aggregate ingest, 144 us measured).  Eight
 //     column tiles share one panel: 0.70 GB.
-template <typename T, int NG, int WD, int AD, int KW, int CT>
+// ADMA (round 5): the activation chunk goes L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: a wave instruction
+//     writes 1 KiB = 8 rows of the 128-B-row image linearly, so the XOR swizzle is applied on the SOURCE side:
+//     lane l of instruction i fetches row 8i + l/8, 16-B slot (l % 8) ^ ((row >> 1) & 7)) instead of through
+//     staging VGPRs and ds_write_b128.  A probe build without any activation staging ran the 70B shapes 10...14 %
+//     faster (profiles/r05_m128_nostage_bound.jsonl): that is what this goes after.  The DMA is inline asm
+//     (through the builtin hipcc makes every ds_read of the activation image wait for the DMA into the OTHER
+//     buffer: attn_tile.hip); the one wait it needs is the counted vmcnt in front of the chunk's barrier -- the
+//     weight / scale loads issued behind it in the same iteration stay in flight, as with the register form.
+template <typename T, int NG, int WD, int AD, int KW, int CT, bool ADMA = false>
 __global__ void __launch_bounds__(64 * CT * KW, (CT == 8 || KW == 2) ? 2 : 3)
 w4a16_gemm_m128_kernel(const GemmKParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,22 +112,52 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
     a_voff[i] = (uint32_t)(2 * (rc * (int)p.lda + slot * 8));
     a_lds[i] = (uint32_t)(row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
   }
+  // ADMA: this wave's DI instructions of a chunk (16 in all, 8 rows each)
+  constexpr int DI = 16 / (CT * KW);
+  static_assert(!ADMA || (AD == 1 && 16 % (CT * KW) == 0), "whole DMA instructions per wave");
+  uint32_t d_voff[DI];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  u32x4 a_rs4 = {0u, 0u, 0u, 0u};
+  if constexpr (ADMA) {
+    const uint64_t ab = (uint64_t)(uintptr_t)p.a;
+    a_rs4 = u32x4{(uint32_t)ab, (uint32_t)((ab >> 32) & 0xffffu), (uint32_t)(((p.M - 1) * p.lda + p.K) * 2), 0x00020000u};
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+      const int row = 8 * (wave * DI + i) + (lane >> 3);
+      const int rc = row < p.M ? row : (int)p.M - 1;
+      const int slot = (lane & 7) ^ ((row >> 1) & 7);
+      d_voff[i] = (uint32_t)(2 * (rc * (int)p.lda + slot * 8));
+    }
+  }
+  auto a_dma = [&](int c, int buf) {   // chunk c (absolute, 64-deep) -> LDS buffer `buf`
+    if constexpr (ADMA) {
+      const uint32_t soff = (uint32_t)min(c, clast) * 128u;
+#pragma unroll
+      for (int i = 0; i < DI; ++i) {
+        const uint32_t dst = lds0 + (uint32_t)(buf * M128_BUF + (wave * DI + i) * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                     :
+                     : "v"(d_voff[i]), "s"(a_rs4), "s"(dst), "s"(soff)
+                     : "memory");
+      }
+    }
+  };
   // this wave's JW words of the lane's 16-B weight vector: bytes [8 kw, 8 kw + 4 JW)
   const uint32_t w_voff = (uint32_t)ntile * 1024u + (uint32_t)lane * 16u + (uint32_t)kw * (4u * JW);
   const uint32_t kt_stride = (uint32_t)n_tiles * 1024u;  // bytes per 64-deep kt block row
   const uint32_t sz_voff = (uint32_t)(ntile * 32 + (lane & 31)) * 4u;
   const uint32_t sz_stride = (uint32_t)p.N * 4u;
 
-  u32x4 areg[AD][AI];
+  u32x4 areg[ADMA ? 1 : AD][ADMA ? 1 : AI];
   auto a_load = [&](int set, int c) {  // chunk c (absolute, 64-deep) -> staging set
     const uint32_t soff = (uint32_t)min(c, clast) * 128u;
 #pragma unroll
-    for (int i = 0; i < AI; ++i)
+    for (int i = 0; i < (ADMA ? 0 : AI); ++i)
       areg[set][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)a_voff[i], (int)soff, 0));
   };
   auto a_store = [&](int set, int buf) {
 #pragma unroll
-    for (int i = 0; i < AI; ++i) *reinterpret_cast<u32x4*>(smem + buf * M128_BUF + a_lds[i]) = areg[set][i];
+    for (int i = 0; i < (ADMA ? 0 : AI); ++i) *reinterpret_cast<u32x4*>(smem + buf * M128_BUF + a_lds[i]) = areg[set][i];
   };
   // weights: plain (cacheable) loads -- the other lane of the decode step re-reads the layer within
   // ~0.4 ms and finds it in the Infinity Cache (w4.hip, round 4)
@@ -164,7 +202,7 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
 
   // ---- prologue: ring filled in steady-state order, chunk c0 staged ------------------------------
   if (nc > 0) {
-    a_load(0, c0);
+    if constexpr (ADMA) a_dma(c0, 0); else a_load(0, c0);
 #pragma unroll
     for (int d = 0; d < WD; ++d) {
       wring[d] = w_load(c0 + d);
@@ -173,8 +211,9 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
     }
     a_store(0, 0);
     if constexpr (AD == 2) a_load(1, c0 + 1);   // (sub-iteration u finds chunk c + 1 in set (u + 1) & 1)
-    bfrag[0] = dequant(wring[0], szr[0], 0);
+    bfrag[0] = dequant(wring[0], szr[0], 0);   // (the compiler's wait for ring slot 0 drains the DMA issued in front of it too)
   }
+  if constexpr (ADMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int mrow = lane & 31, kh = lane >> 5;
@@ -188,7 +227,8 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
       const int c = c0 + cb + u;        // this chunk; its weights sit in ring slot u
       const int buf = u & 1;            // (WD is even: the buffer parity is static too)
       // (past the range: clamped reloads, stored but never read)
-      if constexpr (AD == 2) a_load(u & 1, c + 2); else a_load(0, c + 1);
+      if constexpr (ADMA) a_dma(c + 1, buf ^ 1);   // (the other buffer: last read one barrier ago)
+      else if constexpr (AD == 2) a_load(u & 1, c + 2); else a_load(0, c + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int jj = 0; jj < JW; ++jj) {
@@ -216,6 +256,11 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
         }
       }
       a_store(AD == 2 ? ((u + 1) & 1) : 0, buf ^ 1);
+      // ADMA: chunk c + 1 has landed; the 1 + NGW weight / scale loads issued behind it stay in flight
+      if constexpr (ADMA) {
+        if constexpr (NGW == 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      }
       __syncthreads();
     }
   }
@@ -292,12 +337,12 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
   }
 }
 
-template <typename T, int KW, int CT>
+template <typename T, int KW, int CT, bool ADMA>
 static void launch_m128_t(const GemmKParams& kp, int ng, int wd, int n_blocks, hipStream_t st) {
   const dim3 grid((unsigned)n_blocks), blk(64 * CT * KW);
   const size_t lds = 2 * M128_BUF;
 #define SLM_M128(NGG, WDD) \
-  hipLaunchKernelGGL((w4a16_gemm_m128_kernel<T, NGG, WDD, 1, KW, CT>), grid, blk, lds, st, kp)
+  hipLaunchKernelGGL((w4a16_gemm_m128_kernel<T, NGG, WDD, 1, KW, CT, ADMA>), grid, blk, lds, st, kp)
   if (ng == 2) { if (wd == 4) SLM_M128(2, 4); else SLM_M128(2, 2); }
   else { if (wd == 4) SLM_M128(1, 4); else SLM_M128(1, 2); }
 #undef SLM_M128
@@ -307,17 +352,20 @@ static void launch_m128_t(const GemmKParams& kp, int ng, int wd, int n_blocks, h
 // kw = waves per column tile (1: 256-thread workgroups, 2: 512-thread workgroups with the chunk split in two)
 // (The activation look-ahead of two chunks, AD = 2, measured the same as one on every shape and is not built:
 //  profiles/r05_m128_70b_shapes.jsonl.)
-// ct = column tiles per workgroup (4 / 8; 8 only with kw = 1); n_blocks counts workgroups of ct tiles
-void launch_gemm_m128(const GemmKParams& kp, int dtype, int group_size, int wd, int kw, int ct, int n_blocks, hipStream_t st) {
+// ct = column tiles per workgroup (4 / 8; 8 only with kw = 1); n_blocks counts workgroups of ct tiles;
+// adma = activations by LDS-DMA (built for the 256-column form)
+void launch_gemm_m128(const GemmKParams& kp, int dtype, int group_size, int wd, int kw, int ct, int adma, int n_blocks, hipStream_t st) {
   const int ng = group_size == 32 ? 2 : 1;
   if (dtype == SLM_BF16) {
-    if (ct == 8) launch_m128_t<bf16_tag, 1, 8>(kp, ng, wd, n_blocks, st);
-    else if (kw == 2) launch_m128_t<bf16_tag, 2, 4>(kp, ng, wd, n_blocks, st);
-    else launch_m128_t<bf16_tag, 1, 4>(kp, ng, wd, n_blocks, st);
+    if (ct == 8 && adma) launch_m128_t<bf16_tag, 1, 8, true>(kp, ng, wd, n_blocks, st);
+    else if (ct == 8) launch_m128_t<bf16_tag, 1, 8, false>(kp, ng, wd, n_blocks, st);
+    else if (kw == 2) launch_m128_t<bf16_tag, 2, 4, false>(kp, ng, wd, n_blocks, st);
+    else launch_m128_t<bf16_tag, 1, 4, false>(kp, ng, wd, n_blocks, st);
   } else {
-    if (ct == 8) launch_m128_t<f16_tag, 1, 8>(kp, ng, wd, n_blocks, st);
-    else if (kw == 2) launch_m128_t<f16_tag, 2, 4>(kp, ng, wd, n_blocks, st);
-    else launch_m128_t<f16_tag, 1, 4>(kp, ng, wd, n_blocks, st);
+    if (ct == 8 && adma) launch_m128_t<f16_tag, 1, 8, true>(kp, ng, wd, n_blocks, st);
+    else if (ct == 8) launch_m128_t<f16_tag, 1, 8, false>(kp, ng, wd, n_blocks, st);
+    else if (kw == 2) launch_m128_t<f16_tag, 2, 4, false>(kp, ng, wd, n_blocks, st);
+    else launch_m128_t<f16_tag, 1, 4, false>(kp, ng, wd, n_blocks, st);
   }
 }
 

@@ -186,17 +186,18 @@ def test_wave_specialised_kernel_grid(bits, tune):
 
 
 @pytest.mark.parametrize("bits", ["bf16", "f16"])
-@pytest.mark.parametrize("wd,kw,ct", [(2, 1, 4), (4, 1, 4), (2, 2, 4), (4, 2, 4), (2, 1, 8), (4, 1, 8)])
-def test_m128_kernel_grid(bits, wd, kw, ct, tune):
+@pytest.mark.parametrize("wd,kw,ct,adma", [(2, 1, 4, 0), (4, 1, 4, 0), (2, 2, 4, 0), (4, 2, 4, 0), (2, 1, 8, 0), (4, 1, 8, 0),
+                                           (2, 1, 8, 1), (4, 1, 8, 1)])
+def test_m128_kernel_grid(bits, wd, kw, ct, adma, tune):
     """The 65 <= M <= 128 kernel (w4_m128.hip, round 5: all rows in one workgroup, 64-deep chunks, weight
     ring of 2 / 4 chunks): ragged M (rows clamped, never stored), N not a multiple of 128 (clamped tiles),
     K of 1..9 128-deep units with every split count the plan can pick or a test can force (uneven last
     split included), every group size (32 = two scale groups per chunk, -1 = per channel), both formats,
     act-order (column gather + padded groups), bias, fp32 split-K slabs, fp16 and bf16; kw = 2: the 512-thread
     form whose wave pairs split every chunk and meet in LDS at the end; ct = 8: 256-column workgroups (eight
-    column tiles share the activation panel)."""
+    column tiles share the activation panel); adma = 1: its activations by LDS-DMA instead of through registers."""
     from scalellm_amd import kernels
-    tune(SLM_W4_M128=1, SLM_W4_M128_WD=wd, SLM_W4_M128_KW=kw, SLM_W4_M128_CT=ct)
+    tune(SLM_W4_M128=1, SLM_W4_M128_WD=wd, SLM_W4_M128_KW=kw, SLM_W4_M128_CT=ct, SLM_W4_M128_ADMA=adma)
     i = 0
     for M, N, K, gs, fmt, act, sk in (
             (65, 128, 128, 128, "awq", False, 0), (128, 256, 512, 128, "gptq", False, 0),
@@ -212,7 +213,7 @@ def test_m128_kernel_grid(bits, wd, kw, ct, tune):
         err = _rel_err(out, ref)
         assert err < GEMM_TOL[bits], (M, N, K, gs, fmt, act, sk, err)
     # the kernel is what ran: the general kernel (SLM_W4_M128=0) agrees to summation order only
-    tune(SLM_W4_SPLITK=0, SLM_W4_M128=1, SLM_W4_M128_KW=kw, SLM_W4_M128_CT=ct)
+    tune(SLM_W4_SPLITK=0, SLM_W4_M128=1, SLM_W4_M128_KW=kw, SLM_W4_M128_CT=ct, SLM_W4_M128_ADMA=adma)
     case = helpers.make_quant_case(990, 1024, 512, 128, "awq", bits)
     a_out, ref = _run_gemm(case, bits, 128, bias=False, seed=3)
     tune(SLM_W4_M128=0)

@@ -81,6 +81,8 @@ PLANS = [
     (128, 2048, 1024, 128, dict(SLM_W4_M128=1, SLM_W4_M128_CT=8, SLM_W4_SPLITK=1)),  # ... 256-column workgroups: four (gate, up) wave pairs
     (100, 1024, 448, 32, dict(SLM_W4_M128=1, SLM_W4_M128_CT=8, SLM_W4_SPLITK=2)),    # ... + slabs, clamped pairs
     (65, 1024, 1216, 128, dict(SLM_W4_M128=1, SLM_W4_M128_CT=8, SLM_W4_M128_WD=4)),  # ... N = 19 tile pairs
+    (128, 2048, 1024, 128, dict(SLM_W4_M128=1, SLM_W4_M128_CT=8, SLM_W4_M128_ADMA=1, SLM_W4_SPLITK=1)),  # ... activations by LDS-DMA
+    (100, 1024, 448, 32, dict(SLM_W4_M128=1, SLM_W4_M128_CT=8, SLM_W4_M128_ADMA=1, SLM_W4_SPLITK=2)),
 ]
 
 

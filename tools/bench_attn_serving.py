@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--variants", default="AUTO")
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--hint", action="store_true", help="pass total_kv_len (the uniform-batch hint) on uniform batches")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -72,7 +73,8 @@ def main():
 
                 def run(kc, vc):
                     kernels.paged_kv_varlen_mha(out, q, kc, vc, p.q_cu_seq_lens, p.kv_cu_seq_lens,
-                                                p.block_tables, p.cu_block_lens, None, B, 1, max(kv_lens), D ** -0.5)
+                                                p.block_tables, p.cu_block_lens, None, B, 1, max(kv_lens), D ** -0.5,
+                                                total_kv_len=int(sum(kv_lens)) if (args.hint and shape == "uniform") else 0)
 
                 graphs = []
                 for v in variants:
@@ -99,7 +101,7 @@ def main():
                     t = sorted(times[i])
                     med = t[len(t) // 2]
                     rec = dict(kind="attn_decode_serving", bs=bs, heads=[H, HKV], block=B, kv=shape,
-                               kv_tokens=int(sum(kv_lens)), variant=v or "AUTO", us_med=round(med, 2),
+                               kv_tokens=int(sum(kv_lens)), variant=v or "AUTO", hint=bool(args.hint and shape == "uniform"), us_med=round(med, 2),
                                us_min=round(t[0], 2), algorithmic_bytes=nbytes,
                                gbps=round(nbytes / med / 1e3, 1), frac_of_8TBps=round(nbytes / med / 1e3 / 8000, 4))
                     line = json.dumps(rec)
