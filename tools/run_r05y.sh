@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r05y; mkdir -p $O
+O=gpurun_out/r05y; mkdir -p $O; rm -f $O/*.jsonl
 export TMPDIR=/tmp
 for sp in 0 2 3 4; do
   SLM_ATTN_TILE_SPLITS=$sp OUT=$O/prefill_sp$sp.jsonl timeout 300 python tools/bench_prefill.py > $O/prefill_sp$sp.log 2>&1
