@@ -1044,14 +1044,14 @@ SLM_API int slm_paged_kv_varlen_mha(const slm_attn_args* a, void* stream) {
     if (do_stream && first_tile_rows < 33 && !(uniform_q && max_rows > 32)) {  // (group >= 32: every multi-row sequence already has > 32 rows)
       tk.rows_lo = first_tile_rows;
       tk.rows_hi = 33;
-      rc = launch_attn_tile(tk, a->dtype, max_rows < 32 ? max_rows : 32, st);
+      rc = launch_attn_tile(tk, a->dtype, max_rows < 32 ? max_rows : 32, a->max_kv_len, st);
       if (rc != SLM_OK) return rc;
     }
     if (do_stream && max_rows > 32) {
       // rows <= group (q_len = 1) stay with the token-major kernel also when group > 32 (MQA)
       tk.rows_lo = first_tile_rows > 33 ? first_tile_rows : 33;
       tk.rows_hi = 0x7fffffff;
-      rc = launch_attn_tile(tk, a->dtype, max_rows, st);
+      rc = launch_attn_tile(tk, a->dtype, max_rows, a->max_kv_len, st);
       if (rc != SLM_OK) return rc;
     }
     // the token-major kernel keeps the q_len = 1 sequences

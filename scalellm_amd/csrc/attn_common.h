@@ -67,6 +67,6 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // Returns SLM_OK after launching, or SLM_ERR_UNSUPPORTED when the shape is not covered
 // (the caller then uses the token-major kernel).
 bool attn_tile_supported(int head_dim);
-int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t max_rows, hipStream_t st);
+int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t max_rows, int64_t max_kv_len, hipStream_t st);
 
 }  // namespace slm

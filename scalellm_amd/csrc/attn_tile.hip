@@ -102,13 +102,23 @@ typedef __attribute__((address_space(3))) tr_v4s tr_lds_v4s;
 // still suffice: iteration t reads K[t+1] (buffer (t+1)&1) and V[t] (t&1) and fills K[t+2] -> t&1 (last read
 // by QK^T(t) in iteration t-1) and V[t+1] -> (t+1)&1 (last read by P.V(t-1)).  One barrier per 64 rows as before;
 // 32 more VGPRs (the second score block), which the DMA form freed.  Cross-half exchanges by v_permlane32_swap.
-template <typename T, int HD, int NW, bool PF, bool PLAIN, int KVT = 32, bool DB = false, bool DMA = false, bool PIPE = false>
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) attn_tile_kernel(const AttnKParams p, int tiles_per_seq) {
+// KV2 (round 5, on the PIPE form; plain causal prefill): TWO GROUPS of NW waves share a workgroup's 32 NW query
+// rows and split its KV range -- group g takes the 64-row tiles g, g + 2, g + 4, ... with its own K / V buffers,
+// slot ring and online-softmax state; the two (m, l, O) meet once, through LDS, at the end.  A causal prefill of
+// one long sequence is the serial chain of its longest query tile (32 KV tiles at 2 k: ~55 of the kernel's 59 us
+// whatever the rest of the chip does); splitting the KV range ACROSS workgroups answers that with an fp32 partial
+// per (row, head) through HBM and a combine pass (measured: 60 -> 97 us); inside the workgroup the partial is 16 KiB
+// of LDS per wave and the chain halves for every query tile.  Same waves per SIMD as two 4-wave workgroups.
+template <typename T, int HD, int NW, bool PF, bool PLAIN, int KVT = 32, bool DB = false, bool DMA = false, bool PIPE = false,
+          bool KV2 = false>
+__global__ void __launch_bounds__(64 * NW * (KV2 ? 2 : 1)) __attribute__((amdgpu_waves_per_eu(2))) attn_tile_kernel(const AttnKParams p, int tiles_per_seq) {
   typedef typename TileMfma<T>::frag frag_t;
   static_assert(KVT == 32 || KVT == 64, "KV tile rows");
   static_assert(!DB || PF, "the double-buffered form prefetches through registers");
   static_assert(!DMA || DB, "LDS-DMA staging is built on the double-buffered form");
   static_assert(!PIPE || (DMA && KVT == 64), "the pipelined form is built on the LDS-DMA form");
+  static_assert(!KV2 || PIPE, "the two-group form is built on the pipelined form");
+  constexpr int GW = KV2 ? 2 : 1;     // wave groups sharing the query rows (each its own KV tiles and LDS buffers)
   constexpr int TILE_KV = KVT;
   constexpr int NH = KVT / 32;        // 32-row S^T blocks per tile
   constexpr int KSTEPS = HD / 16;     // MFMA k-steps of the QK product
@@ -118,13 +128,15 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
   constexpr int VH_BYTES = (HD / 16) * V_SUB_STRIDE;  // V image of one 32-row half tile
   constexpr int V_BYTES = NH * VH_BYTES;
   constexpr int NBUF = DB ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) char k_lds[NBUF * K_BYTES];
-  __shared__ __attribute__((aligned(16))) char v_lds[NBUF * V_BYTES];
+  __shared__ __attribute__((aligned(16))) char k_lds[GW * NBUF * K_BYTES];
+  __shared__ __attribute__((aligned(16))) char v_lds[GW * NBUF * V_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int nthreads = 64 * NW;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = KV2 ? wave_all / NW : 0;            // wave group (KV2)
+  const int wave = KV2 ? wave_all % NW : wave_all;    // wave inside its group = 32-row block of the query tile
+  constexpr int nthreads = 64 * NW;                   // (threads of ONE group: the row / staging arithmetic below)
   constexpr int ITEMS = TILE_KV * (HD / 8) / nthreads;  // 16-B staging items per thread per tile
   const int hh = lane >> 5;
   const int l31 = lane & 31;
@@ -141,7 +153,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
     const int hb = p.n_kv_heads * p.batch;
     const int n_items = tiles_per_seq * hb;
     const int half = (n_items + 1) / 2;
-    const int r = bid < half ? bid : n_items - 1 - (bid - half);  // rank by descending query tile
+    // (KV2: one workgroup per CU at a time, handed out in order: longest first)
+    const int r = KV2 ? bid : (bid < half ? bid : n_items - 1 - (bid - half));  // rank by descending query tile
     bid = (tiles_per_seq - 1 - r / hb) + tiles_per_seq * (r % hb);
   }
   const int tile = bid % tiles_per_seq;
@@ -166,6 +179,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
   const int head = kvh * G + (jvalid ? jrow % G : 0);
   const int diag = kv_len - q_len + tq;  // last visible kv index of this row (causal)
   if (kv_len <= 0) {
+    if (grp != 0) return;   // (workgroup-uniform condition: nobody reaches a barrier)
     // empty history (workgroup-uniform): this kernel owns the rows, so it publishes the empty
     // result -- a zero output row, or a zero-weight partial (l = 0, O = 0) for the combine kernel,
     // whose loads are unconditional (an unwritten partial would be combined as garbage)
@@ -307,14 +321,21 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
   constexpr int NSUB = HD / 16;                       // V sub-tiles per 32-row half
   constexpr int VI = DMA ? (NH * NSUB) / NW : 1;      // V instructions per wave and tile
   static_assert(!DMA || ((TILE_KV / ROWS_KI) % NW == 0 && (NH * NSUB) % NW == 0), "whole instructions per wave");
-  __shared__ int slot_lds[PIPE ? 3 * TILE_KV : DMA ? 2 * TILE_KV : 1];   // cache slots of the rows of two (PIPE: three) tiles
+  __shared__ int slot_lds[PIPE ? GW * 3 * TILE_KV : DMA ? 2 * TILE_KV : 1];   // cache slots of the rows of two (PIPE: three) tiles
   // (the DMA is issued as inline asm, invisible to the compiler's waitcnt bookkeeping: through the builtin
   //  hipcc makes every ds_read of k_lds / v_lds wait for the wave's own outstanding DMA into the OTHER
   //  buffer -- it cannot tell the halves of one LDS array apart -- which serialises copy and compute; the
   //  one wait the data needs is the explicit vmcnt(0) in front of the tile's barrier)
   u32x4 k_rs = {0u, 0u, 0u, 0u}, v_rs = {0u, 0u, 0u, 0u};
-  int k_row[KI], v_row[VI];
-  int k_voff[KI], v_voff[VI];
+  // per-lane parts of the DMA addressing (two VGPRs for K, two for V); everything that depends on the wave and
+  // on the instruction index is wave-uniform and stays scalar:
+  //   K instruction j of the wave covers rows R0 + ROWS_KI j + kl_row (R0 = ROWS_KI KI wave), 16-B slot
+  //   (lane % NSLOT) ^ (row % NSLOT); R0 + ROWS_KI j is a multiple of ROWS_KI > kl_row, so the XOR splits into a lane
+  //   part and a scalar part;  V instruction ii covers rows 32 (ii / NSUB) + lane / 2, columns 2 (ii % NSUB) + lane % 2
+  const int kl_row = lane / NSLOT;
+  const int kl_voff = 16 * ((lane % NSLOT) ^ kl_row);
+  const int vl_row = lane >> 1;
+  const int vl_voff = 16 * (lane & 1);
   const uint32_t k_lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)k_lds;
   const uint32_t v_lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)v_lds;
   if constexpr (DMA) {
@@ -322,19 +343,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
     const uint64_t kb64 = (uint64_t)(uintptr_t)kbase, vb64 = (uint64_t)(uintptr_t)vbase;
     k_rs = u32x4{(uint32_t)kb64, (uint32_t)((kb64 >> 32) & 0xffffu) | (k_sb << 16), 0x7fffffffu, 0x00020000u};
     v_rs = u32x4{(uint32_t)vb64, (uint32_t)((vb64 >> 32) & 0xffffu) | (v_sb << 16), 0x7fffffffu, 0x00020000u};
-#pragma unroll
-    for (int j = 0; j < KI; ++j) {
-      k_row[j] = ROWS_KI * (wave * KI + j) + lane / NSLOT;
-      k_voff[j] = 16 * ((lane % NSLOT) ^ (k_row[j] & (NSLOT - 1)));
-    }
-#pragma unroll
-    for (int j = 0; j < VI; ++j) {
-      const int ii = wave * VI + j;
-      v_row[j] = 32 * (ii / NSUB) + (lane >> 1);
-      v_voff[j] = 16 * (2 * (ii % NSUB) + (lane & 1));
-    }
   }
-  auto dma16 = [&](const u32x4& rs, uint32_t dst, int vindex, int voff) {
+  auto dma16 = [&](const u32x4& rs, uint32_t dst, int vindex, int voff) __attribute__((always_inline)) {
     const u32x2 iv = {(uint32_t)vindex, (uint32_t)voff};
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 idxen offen lds"
                  :
@@ -342,33 +352,36 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
                  : "memory");
   };
   // K / V rows of the tile whose slots sit in slot_lds[sb] -> LDS buffer `buf`
-  auto dma_k = [&](int buf, int sb) {
+  auto dma_k = [&](int buf, int sb) __attribute__((always_inline)) {
     if constexpr (DMA) {
       int ks[KI];
 #pragma unroll
-      for (int j = 0; j < KI; ++j) ks[j] = slot_lds[sb * TILE_KV + k_row[j]];
+      for (int j = 0; j < KI; ++j) ks[j] = slot_lds[sb * TILE_KV + ROWS_KI * (wave * KI + j) + kl_row];
 #pragma unroll
-      for (int j = 0; j < KI; ++j) dma16(k_rs, k_lds0 + buf * K_BYTES + (wave * KI + j) * 1024, ks[j], k_voff[j]);
-    }
-  };
-  auto dma_v = [&](int buf, int sb) {
-    if constexpr (DMA) {
-      int vs[VI];
-#pragma unroll
-      for (int j = 0; j < VI; ++j) vs[j] = slot_lds[sb * TILE_KV + v_row[j]];
-#pragma unroll
-      for (int j = 0; j < VI; ++j) {
-        const int ii = wave * VI + j;
-        dma16(v_rs, v_lds0 + buf * V_BYTES + (ii / NSUB) * VH_BYTES + v_sub_base(ii % NSUB), vs[j], v_voff[j]);
+      for (int j = 0; j < KI; ++j) {
+        const int r0 = ROWS_KI * (wave * KI + j);   // (wave-uniform)
+        dma16(k_rs, k_lds0 + buf * K_BYTES + (wave * KI + j) * 1024, ks[j], kl_voff ^ (16 * (r0 & (NSLOT - 1))));
       }
     }
   };
-  auto dma_tile = [&](int buf, int sb) {
+  auto dma_v = [&](int buf, int sb) __attribute__((always_inline)) {
+    if constexpr (DMA) {
+      int vs[VI];
+#pragma unroll
+      for (int j = 0; j < VI; ++j) vs[j] = slot_lds[sb * TILE_KV + 32 * ((wave * VI + j) / NSUB) + vl_row];
+#pragma unroll
+      for (int j = 0; j < VI; ++j) {
+        const int ii = wave * VI + j;               // (wave-uniform)
+        dma16(v_rs, v_lds0 + buf * V_BYTES + (ii / NSUB) * VH_BYTES + v_sub_base(ii % NSUB), vs[j], vl_voff + 32 * (ii % NSUB));
+      }
+    }
+  };
+  auto dma_tile = [&](int buf, int sb) __attribute__((always_inline)) {
     dma_k(buf, sb);
     dma_v(buf, sb);
   };
   // one row per thread (threads 0..63): the slot of row kt0 + tid (clamped: masked below, in bounds)
-  auto slot_lookup = [&](int kt0) -> int {
+  auto slot_lookup = [&](int kt0) __attribute__((always_inline)) -> int {
     const int row = min(kt0 + (tid & (TILE_KV - 1)), min(wg_hi_s, kv_len) - 1);
     return p.bt[bcu0 + (row >> p.block_shift)] + (row & p.block_mask);
   };
@@ -383,12 +396,12 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
     float cm[2] = {1.0f, 1.0f};   // multiplier of a block's scores inside the exponent's fma (1 once a masked block was rewritten)
     float l_lane = 0.f;           // this lane's share of the row sum (the lane halves meet once, at the end)
     const int dmin = kv_len - q_len + (row0 + wave * 32) / G;   // smallest diagonal of the wave's rows
-    auto xhalf = [&](float x, bool take_max) {   // combine with the other lane half
+    auto xhalf = [&](float x, bool take_max) __attribute__((always_inline)) {   // combine with the other lane half
       const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
       const float a = __uint_as_float(r[0]), b = __uint_as_float(r[1]);
       return take_max ? fmaxf(a, b) : a + b;
     };
-    auto qk_step = [&](auto pc, int kbuf, int s) {   // k-step s of sc[P] = K[kbuf] . Q^T
+    auto qk_step = [&](auto pc, int kbuf, int s) __attribute__((always_inline)) {   // k-step s of sc[P] = K[kbuf] . Q^T
       constexpr int P = decltype(pc)::value;
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
@@ -398,7 +411,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
         sc[P][h] = TileMfma<T>::run(__builtin_bit_cast(frag_t, kv4), qf[s], sc[P][h]);
       }
     };
-    auto zero = [&](auto pc) {
+    auto zero = [&](auto pc) __attribute__((always_inline)) {
       constexpr int P = decltype(pc)::value;
 #pragma unroll
       for (int h = 0; h < NH; ++h)
@@ -406,7 +419,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
         for (int r = 0; r < 16; ++r) sc[P][h][r] = 0.f;
     };
     // scale / soft-cap / alibi / mask of block P (tile at kt0), its row max, lazy rescale of O and l
-    auto decide = [&](auto pc, int kt0) {
+    auto decide = [&](auto pc, int kt0) __attribute__((always_inline)) {
       constexpr int P = decltype(pc)::value;
       const bool interior = PLAIN && p.scale_log2 > 0.f && kt0 + TILE_KV <= kv_len && kt0 + TILE_KV - 1 <= dmin;
       float mloc = -INFINITY;
@@ -493,51 +506,102 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
     };
     if (wg_lo < wg_hi_s) {
       const int nt = (wg_hi_s - wg_lo + TILE_KV - 1) / TILE_KV;
-      if (tid < TILE_KV) {
-        slot_lds[tid] = slot_lookup(wg_lo);
-        slot_lds[TILE_KV + tid] = slot_lookup(wg_lo + TILE_KV);
-        slot_lds[2 * TILE_KV + tid] = slot_lookup(wg_lo + 2 * TILE_KV);
+      // this group's tiles: grp, grp + GW, ...  (i-th one at kt_of(i)); every group runs nt_loop iterations of
+      // the loop below (the barriers are the workgroup's), the last of which may be empty for group 1
+      const int nt_g = (nt - grp + GW - 1) / GW;
+      const int nt_loop = (nt + GW - 1) / GW;
+      const int gb = 2 * grp, sbase = 3 * grp;     // first LDS buffer / slot-ring entry of the group
+      auto kt_of = [&](int i) __attribute__((always_inline)) { return wg_lo + (i * GW + grp) * TILE_KV; };
+      if (wave == 0) {
+        slot_lds[(sbase + 0) * TILE_KV + lane] = slot_lookup(kt_of(0));
+        slot_lds[(sbase + 1) * TILE_KV + lane] = slot_lookup(kt_of(1));
+        slot_lds[(sbase + 2) * TILE_KV + lane] = slot_lookup(kt_of(2));
       }
       __syncthreads();
-      dma_tile(0, 0);
-      dma_k(1, 1);
+      dma_tile(gb + 0, sbase + 0);
+      dma_k(gb + 1, sbase + 1);
 #pragma unroll
       for (int s = 0; s < KSTEPS; ++s) asm volatile("" ::"v"(qf[s]));   // (Q is waited for here, not in the loop: see DMA)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      zero(P0{});
+      if (nt_g > 0) {
+        zero(P0{});
 #pragma unroll
-      for (int s = 0; s < KSTEPS; ++s) qk_step(P0{}, 0, s);
-      decide(P0{}, wg_lo);
+        for (int s = 0; s < KSTEPS; ++s) qk_step(P0{}, gb + 0, s);
+        decide(P0{}, kt_of(0));
+      }
       __syncthreads();   // K buffer 0 is refilled at the top of the first iteration: every wave is done with it
-      int m3 = 0;        // t mod 3
-      // tile t: its scores in sc[P]
-      auto body = [&](auto pc, int t) {
+      int m3 = 0;        // i mod 3
+      // the group's i-th tile: its scores in sc[P]
+      auto body = [&](auto pc, int i) __attribute__((always_inline)) {
         constexpr int P = decltype(pc)::value;
-        const int kt0 = wg_lo + t * TILE_KV;
-        const bool more = t + 1 < nt;
-        // wave 0 looks up the slots of tile t + 3 (one row per lane), in FRONT of the DMA: see DMA
+        const int kt0 = kt_of(i);
+        const bool more = i + 1 < nt_g;
+        // wave 0 of the group looks up the slots of its tile i + 3 (one row per lane), in FRONT of the DMA: see DMA
         int slot_next = 0;
-        if (wave == 0) slot_next = slot_lookup(kt0 + 3 * TILE_KV);
+        if (wave == 0) slot_next = slot_lookup(kt_of(i + 3));
         const int m3p1 = m3 == 2 ? 0 : m3 + 1, m3p2 = m3 == 0 ? 2 : m3 - 1;
-        dma_k(t & 1, m3p2);          // K[t+2]
-        dma_v((t + 1) & 1, m3p1);    // V[t+1]
+        dma_k(gb + (i & 1), sbase + m3p2);          // K of tile i + 2
+        dma_v(gb + ((i + 1) & 1), sbase + m3p1);    // V of tile i + 1
         u32x4 pb[2 * NH];
-        if (more) step_a(pc, std::true_type{}, (t + 1) & 1, pb);
-        else step_a(pc, std::false_type{}, 0, pb);
-        step_b(t & 1, pb);
-        if (more) decide(std::integral_constant<int, 1 - P>{}, kt0 + TILE_KV);
-        if (wave == 0) slot_lds[m3 * TILE_KV + lane] = slot_next;   // tile t + 3 takes tile t's place in the ring
+        if (i < nt_g) {
+          if (more) step_a(pc, std::true_type{}, gb + ((i + 1) & 1), pb);
+          else step_a(pc, std::false_type{}, 0, pb);
+        }
+        if constexpr (KV2) __syncthreads();   // (between the segments: the other group is half an iteration away)
+        if (i < nt_g) {
+          step_b(gb + (i & 1), pb);
+          if (more) decide(std::integral_constant<int, 1 - P>{}, kt_of(i + 1));
+        }
+        if (wave == 0) slot_lds[(sbase + m3) * TILE_KV + lane] = slot_next;   // tile i + 3 takes tile i's place in the ring
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         m3 = m3p1;
       };
-      for (int t = 0; t < nt; t += 2) {
-        body(P0{}, t);
-        if (t + 1 < nt) body(P1{}, t + 1);
+      // KV2, PING-PONG: the two groups run half an iteration apart -- group 1 passes one extra barrier in front of
+      // the loop (group 0 one behind it), and the body has a second barrier between its A and B segments: while
+      // one group is in segment A of its tile (QK^T of the next tile || this tile's exponentials: matrix + VALU)
+      // the other is in segment B of ITS tile (P.V + the next row max: matrix, little VALU).  In step -- both in A,
+      // then both in B -- the two waves of a SIMD want the VALU at the same time and the matrix pipe at the same
+      // time.  Same code for both groups inside the loop; a group's DMA is issued at the top of its A segment and
+      // waited for at the bottom of its B segment, two barriers in front of the A segment that reads it.
+      if constexpr (KV2) {
+        if (grp == 1) __syncthreads();
+      }
+      for (int i = 0; i < nt_loop; i += 2) {
+        body(P0{}, i);
+        if (i + 1 < nt_loop) body(P1{}, i + 1);
+      }
+      if constexpr (KV2) {
+        if (grp == 0) __syncthreads();
       }
     }
     l_run = xhalf(l_lane, false);
+    if constexpr (KV2) {
+      // the two groups' (m, l, O) of a query row meet in LDS (the V buffers: every wave is behind the loop's last
+      // barrier): group 1 publishes, group 0 merges and carries on to the epilogue
+      float* mg = reinterpret_cast<float*>(v_lds) + wave * ((DT * 16 + 2) * 64) + lane;
+      __syncthreads();
+      if (grp == 1) {
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mg[(d * 16 + r) * 64] = oacc[d][r];
+        mg[(DT * 16) * 64] = m_run;
+        mg[(DT * 16 + 1) * 64] = l_run;
+      }
+      __syncthreads();
+      if (grp == 1) return;
+      const float m1 = mg[(DT * 16) * 64], l1 = mg[(DT * 16 + 1) * 64];
+      const float m_new = fmaxf(m_run, m1);
+      const float a0 = fast_exp2(m_run - m_new), a1 = fast_exp2(m1 - m_new);
+      m_run = m_new;
+      l_run = l_run * a0 + l1 * a1;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = oacc[d][r] * a0 + mg[(d * 16 + r) * 64] * a1;
+    }
   } else {
   if constexpr (DMA) {
     if (wg_lo < wg_hi_s) {
@@ -777,7 +841,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2)
 bool attn_tile_supported(int head_dim) { return head_dim == 64 || head_dim == 128; }
 
 // rows = largest q_len * group this launch has to cover (query rows per (sequence, kv head))
-int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t rows, hipStream_t st) {
+int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t rows, int64_t max_kv_len, hipStream_t st) {
   if (!attn_tile_supported(kp.head_dim)) return SLM_ERR_UNSUPPORTED;
   if (rows < 1) return SLM_ERR_UNSUPPORTED;
   int nw = (int)((rows + 31) / 32);
@@ -795,6 +859,14 @@ int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t rows, hipStream_t
   // the cross-tile pipeline: the instantiations without soft-cap / alibi / window (with them the head_dim-128 form
   // spills 22...31 VGPRs at its 256-register cap); SLM_ATTN_TILE_PF = 5: LDS-DMA staging without it
   const bool pipe = pf_mode != 5;
+  // two wave groups per query tile (KV2): measured (profiles/r05_prefill_tile_kv2.jsonl) it LOSES wherever the grid
+  // fills the chip with 4-wave workgroups -- eight waves on one barrier, even half an iteration apart, run a tile
+  // slower than two independent workgroups (chunked 8 x 256: 915 -> 793 TFLOP/s, causal 4 x 1024: 561 -> 445, 1 x 2048
+  // the same) -- and wins where the 4-wave grid leaves CUs empty: one 256-token chunk over an 8 k history 65 -> 58 us.
+  // Automatic only there (fewer workgroups than CUs); SLM_ATTN_TILE_KV2: 1 = always where the form exists, 0 = never.
+  const int kv2_mode = tune_get(TUNE_ATTN_TILE_KV2, -1);
+  (void)max_kv_len;
+  const bool kv2 = kv2_mode > 0 || (kv2_mode < 0 && grid <= 256);
   const bool dma = pf_mode != 4 && 2 * kp.k_ss < 16384 && 2 * kp.v_ss < 16384 && 2 * kp.k_ss > 0 && 2 * kp.v_ss > 0;
 #define SLM_TILE(TT, HDD, NWW)                                                                    \
   do {                                                                                            \
@@ -806,7 +878,8 @@ int launch_attn_tile(const AttnKParams& kp, int dtype, int64_t rows, hipStream_t
   // 32-row single-buffer form for A/B runs)
 #define SLM_TILE64(TT, HDD, NWW)                                                                  \
   do {                                                                                            \
-    if (plain && dma && pipe) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, true, 64, true, true, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
+    if (plain && dma && pipe && kv2 && NWW == 4 && HDD == 128) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW == 4 && HDD == 128 ? 4 : NWW, true, true, 64, true, true, true, NWW == 4 && HDD == 128>), g, dim3(blk.x * 2), 0, st, kp, (int)tiles_per_seq); \
+    else if (plain && dma && pipe) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, true, 64, true, true, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
     else if (plain && dma) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, true, 64, true, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
     else if (dma) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, false, 64, true, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
     else if (plain) hipLaunchKernelGGL((attn_tile_kernel<TT, HDD, NWW, true, true, 64, true>), g, blk, 0, st, kp, (int)tiles_per_seq); \
