@@ -568,6 +568,16 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
     const int64_t tiles16 = ((a->M + 255) / 256) * ((a->N + 255) / 256);
     const int64_t rounds = (tiles16 + 255) / 256;
     if (a_fits && tiles16 >= 224 && tiles16 * 100 >= rounds * 256 * 87) mt = 16;
+    // ... and when the 256 x 128 tiles need MORE rounds than they save (round 5, M = 2648 -- the mixed step's row
+    // count: o 4096 x 4096 = 176 / 352 tiles: one 69 %-full round of 256 x 256 tiles 102.6 us against two rounds of
+    // 256 x 128 tiles 117.4; down 340.8 against 382.8): a 256 x 128 tile takes 0.58 of a 256 x 256 tile's time
+    // (profiles/r05_gemm_large_m.jsonl; layer chain 1282 -> 1192 us at M = 2648, 1400 -> 1322 at 3072,
+    // the mixed step 55.1 -> 52.6 ms)
+    const int64_t rounds8 = (tiles8 + 255) / 256;
+    // (and only with its rounds >= 65 % full: at 56 % -- qkv at M = 1536, 144 tiles -- the layer chain LOSES 5.6 %)
+    if (a_fits && mt == 8 && rounds8 >= 2 && rounds * 100 < rounds8 * 58 && tiles16 * 100 >= rounds * 256 * 65 &&
+        tune_get(TUNE_W4_XL_MODEL, 1) != 0)
+      mt = 16;
   }
   // M <= 4: dot2 GEMV (w4_gemv.hip); M <= 32: the lean weight-streaming kernel (w4_small.hip)
   // (measured: the GEMV wins on every layer shape at M = 1 and loses on some at M = 2..4, so the
