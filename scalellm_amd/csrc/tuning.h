@@ -16,7 +16,7 @@ enum TuneKey : int {
   TUNE_ATTN_HGW,          // SLM_ATTN_HGW          head groups per workgroup cap
   TUNE_ATTN_TILE,         // SLM_ATTN_TILE         0 = never use the MFMA tile kernel
   TUNE_ATTN_TILE_SPLITS,  // SLM_ATTN_TILE_SPLITS  forced split count of the tile kernel
-  TUNE_ATTN_TILE_PF,      // SLM_ATTN_TILE_PF      tile kernel prefetch variant
+  TUNE_ATTN_TILE_PF,      // SLM_ATTN_TILE_PF      tile kernel staging form: 0 = no prefetch, 2 = 32-row single-buffer tiles, 4 = register-staged 64-row tiles, 5 = LDS-DMA without the cross-tile pipeline (default 1: LDS-DMA + pipeline where they exist)
   TUNE_ATTN_U,            // SLM_ATTN_U            K/V register ring depth (2/4)
   TUNE_ATTN_NT,           // SLM_ATTN_NT           non-temporal KV loads on/off
   TUNE_ATTN_TILE_DECODE,  // SLM_ATTN_TILE_DECODE  min GQA group at which q_len = 1 goes to the tile kernel (default 8, 0 = never)
