@@ -416,3 +416,29 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
         assert int(val) == want, f"{cname}.{field}: C says {val}, ctypes says {want}"
         seen += 1
     assert seen == sum(len(ct._fields_) + 1 for ct in structs.values())
+
+
+def test_tuning_knob_names_follow_the_enum_order():
+    """capi.hip's name table is indexed by tuning.h's enum: a knob added in one place and not (or elsewhere) in
+    the other would silently steer a different knob.  Every enumerator carries its SLM_* name in its comment;
+    the two sequences must be identical."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scalellm_amd", "csrc")
+    enum_names = []
+    in_enum = False
+    for line in open(os.path.join(root, "tuning.h")):
+        if re.match(r"\s*enum\b", line):
+            in_enum = True
+            continue
+        if in_enum:
+            m = re.match(r"\s*(TUNE_\w+)\s*(=\s*0)?\s*,\s*//\s*(SLM_\w+)", line)
+            if m:
+                enum_names.append(m.group(3))
+            elif "TUNE_COUNT" in line:
+                break
+    src = open(os.path.join(root, "capi.hip")).read()
+    table = src[src.index("kTuneNames[TUNE_COUNT]"):]
+    table = table[:table.index("};")]
+    table_names = re.findall(r'"(SLM_\w+)"', table)
+    assert len(enum_names) > 30 and enum_names == table_names, (enum_names, table_names)
