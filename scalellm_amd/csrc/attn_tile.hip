@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(64 * NW * (KV2 ? 2 : 1)) __attribute__((amdgpu
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 idxen offen lds"
                  :
                  : "v"(iv), "s"(rs), "s"(dst)
-                 : "memory");
+                 : "memory", "m0");
   };
   // K / V rows of the tile whose slots sit in slot_lds[sb] -> LDS buffer `buf`
   auto dma_k = [&](int buf, int sb) __attribute__((always_inline)) {

@@ -120,8 +120,8 @@ StateDict LlamaForCausalLMHip::select_qkv(const StateDict& layer_sd) const {
   const int64_t n_kv = args_.n_kv_heads, ratio = kv_replication_;
   return layer_sd.select_with_transform("self_attn.", [n_kv, ratio](const std::string& name, const torch::Tensor& t) {
     if (name.rfind("k_proj.", 0) != 0 && name.rfind("v_proj.", 0) != 0) return t;
-    if (t.dim() == 1) return t.reshape({n_kv, -1}).repeat_interleave(ratio, 0).reshape({-1}).contiguous();
-    if (name.find("g_idx") != std::string::npos) return t;  // (rows, not output features)
+    if (name.find("g_idx") != std::string::npos) return t;  // (1-D over ROWS, not output features: unchanged)
+    if (t.dim() == 1) return t.reshape({n_kv, -1}).repeat_interleave(ratio, 0).reshape({-1}).contiguous();  // bias
     const int64_t rows = t.size(0);
     return t.reshape({rows, n_kv, -1}).repeat_interleave(ratio, 1).reshape({rows, -1}).contiguous();
   });

@@ -450,7 +450,13 @@ __global__ void __launch_bounds__(256, (POST && PC * MT == 4 && MT < 4) ? 1 : 2)
         if (row < p.M) {
           if (p.split_k == 1)
             reinterpret_cast<uint16_t*>(p.c)[row * p.ldc + n] = pack1<T>(acc[t][m][r] + bv);
-          else
+          else if (p.ks_dbg & 8) {  // (probe bit 8: tile-contiguous slab layout -- consumers not adapted, timing only)
+            const int64_t tile = (int64_t)mb * p.n_nblocks + nb;
+            const int rit = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int cit = (wave * NTW + t) * 32 + (lane & 31);
+            p.part[(int64_t)ks * p.M * p.N + tile * (BM * 128 * NTW) + rit * (128 * NTW) + cit] = acc[t][m][r];
+          } else if ((p.ks_dbg & 16) && ks != 0) {  // (probe bit 16: only slice 0 stores its slab: the traffic of an in-place reduce)
+          } else if (!(p.ks_dbg & 4))  // (probe bit 4 of SLM_W4_KS_DBG: no slab stores -- WRONG results, timing only)
             p.part[((int64_t)ks * p.M + row) * p.N + n] = acc[t][m][r];
         }
       }

@@ -80,13 +80,9 @@ constexpr int KS_SLOTS = 4;  // partial-tile slots in LDS (see the slot arithmet
 // for ONE chunk per wave: K is split over the 8 waves x ceil(K / 1024) workgroups (fp32 slabs, summed
 // by the consumer or the reduce kernel).  A 64 x 32 partial tile goes through the LDS meeting as two
 // consecutive entries of the slot sequence (2t, 2t + 1).
-// AF (round 5): the activations arrive FRAGMENT-MAJOR (SLM_W4_A_FRAG: a_frag[K/16][ceil(M/32)][64 lanes][16 B], lane
-// l of block (j, mt) = row 32 mt + (l & 31), k = 16 j + 8 (l >> 5) .. + 7 -- exactly one MFMA A operand per KiB,
-// written that way by the producer: slm_rms_norm_frag, the attention and SiLU epilogues).  The prologue is then
-// 8 coalesced 1-KiB loads per chunk straight into the fragment registers: no LDS-DMA issue (32 x s_mov m0 +
-// buffer_load ... lds), no staging round trip, no fragment reads, no swizzle -- the part of the prologue that
-// took the same 8.8 k of 12.7 k cycles with every load disabled (profiles/r03_ks_timeline.jsonl).
-template <typename T, int CW, int NG, int NW, bool TL = false, bool PK = false, int MT = 1, bool AF = false>
+// (A fragment-major activation layout was measured in round 5 -- 3.6 % -- and is kept only as
+// tools/probes/experiments/w4_ks_fragment_major_activations.diff.)
+template <typename T, int CW, int NG, int NW, bool TL = false, bool PK = false, int MT = 1>
 __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef typename Mfma<T>::frag frag_t;
@@ -232,28 +228,7 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
         xg[mt][c * NG + g] = xs + __shfl_xor(xs, 32, 64);
       }
     };
-    if constexpr (AF) {
-      // fragment-major activations: block (k-step J = 8 (cw0 + c) + j, row tile mt) is one contiguous KiB
-      const int mtiles = (int)((p.M + 31) >> 5);
-      const __amdgpu_buffer_rsrc_t af_rs = ks_rsrc(p.a, (uint32_t)((p.K >> 4) * (int64_t)mtiles * 1024));
-      const uint32_t af_voff = (uint32_t)lane * 16u;
-#pragma unroll
-      for (int v = 0; v < VC; ++v) {
-        const int c = v / MT, mt = v % MT;
-        const int cabs = cw0 + c;
-        const bool on = cabs <= clast && mt < mtiles && !(p.ks_dbg & 1);   // chunks past K: zeros (out-of-range loads)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const uint32_t soff = on ? (uint32_t)(((cabs * 8 + j) * mtiles + mt) * 1024) : KS_OOB;
-          act[mt][c][j] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(af_rs, (int)af_voff, (int)soff, 0));
-        }
-      }
-      stamp(2);
-      // counters zeroed (top of the kernel) before anybody can publish a tile
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-      for (int v = 0; v < VC; ++v) xsum_chunk(v);
-    } else {
+    {
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     // hand-made resource words for the asm DMA: base, base_hi (stride 0), bytes, flags
     const uint64_t abits = reinterpret_cast<uint64_t>(p.a);
@@ -289,7 +264,7 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
           asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
                        :
                        : "v"(dma_voff[mt][i]), "s"(stage_base(v & 1, i)), "s"(a_rs4), "s"(a_soff)
-                       : "memory");
+                       : "memory", "m0");
     };
     // fragment (row m = lane & 31, octet 2j + h) sits at row group m >> 2, row-in-group m & 3,
     // position (2j + h) ^ (m & 15) = 2j ^ ((m & 15) ^ h)
@@ -342,7 +317,7 @@ __global__ void __launch_bounds__(NW * 64, 2) w4a16_gemm_ks_kernel(const GemmKPa
     }
     xsum_chunk(VC >= 2 ? VC - 2 : 0);
     if (VC >= 2) xsum_chunk(VC - 1);
-    }  // (!AF)
+    }
     // the partial-slot writes of tile 0 reuse the staging memory: the fragment reads are done (their
     // values fed the MFMAs above)
 #pragma unroll

@@ -138,7 +138,7 @@ w4a16_gemm_m128_kernel(const GemmKParams p) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
                      :
                      : "v"(d_voff[i]), "s"(a_rs4), "s"(dst), "s"(soff)
-                     : "memory");
+                     : "memory", "m0");
       }
     }
   };

@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(512, 2) w4a16_gemm_ws_kernel(const GemmKParams
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
                    :
                    : "v"(a_off[i]), "s"(dst), "s"(abase + (int64_t)ua * 64)
-                   : "memory");
+                   : "memory", "m0");
     };
     // Step g (from -6): DMA for A unit g+6, dequant + write of B unit g+3, publish A unit g+2 and
     // B unit g+2.  Nothing on the critical path waits for a latency: the B writes of a step are

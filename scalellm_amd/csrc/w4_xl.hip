@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(512, 2) w4a16_gemm_xl_kernel(const GemmKParams
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
                  :
                  : "v"(a_off[i]), "s"(dst), "s"(abase + (int64_t)ua * 64)
-                 : "memory");
+                 : "memory", "m0");
   };
 
   // ---- weights: this wave dequantises column tile `wave` of the block's 8 ----

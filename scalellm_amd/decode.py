@@ -320,7 +320,9 @@ class LlamaDecodeStep:
             h0 = two_lane_split(s, self.n_heads, self.n_kv_heads, self.pa.world_size,
                                 self.lanes_min if self.lanes_min > 0 else 1, n_tokens, n_tokens, 1, 1 << 30,
                                 tp_lanes_ok=True)
-        for lane, rows in ((0, n_tokens), (1, n_tokens - h0)) if 0 < h0 < n_tokens else ((0, n_tokens),):
+        # (lane 1 of ANY batch of T <= n_tokens rows: T - h0(T) <= T / 2 -- not n_tokens - h0(n_tokens): reserve(200)
+        # splits 128 / 72, a later 192-row step 96 / 96)
+        for lane, rows in ((0, n_tokens), (1, (n_tokens + 1) // 2)) if 0 < h0 < n_tokens else ((0, n_tokens),):
             with kernels.workspace_lane(lane):
                 kernels.reserve_workspace(need_for(rows), self.device, deferred_nbytes=16 * rows * widest * 4)
         if 0 < h0 < n_tokens and self._side_stream is None:
@@ -418,13 +420,23 @@ class LlamaDecodeStep:
             self.reserve_workspaces(n_tokens, kv_len)
             o_buf, down_buf = self.buf["o"][:n_tokens], self.buf["down"][:n_tokens]
             self.buf["resid"][:n_tokens].normal_()
+            import gc
             for lanes in (1, 2):
                 with self.graph_variant((lanes, True)):
                     self._run_layers(n_tokens, positions, params, o_buf, down_buf, None)   # warm-up outside capture
                     torch.cuda.synchronize(self.device)
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        self._run_layers(n_tokens, positions, params, o_buf, down_buf, None)
+                    # no cyclic collection while the stream captures (model_runner._Graph.capture: a collector run
+                    # finalises the events of an earlier two-lane step on the capturing thread -> runtime abort)
+                    gc.collect()
+                    gc_was_on = gc.isenabled()
+                    gc.disable()
+                    try:
+                        with torch.cuda.graph(g):
+                            self._run_layers(n_tokens, positions, params, o_buf, down_buf, None)
+                    finally:
+                        if gc_was_on:
+                            gc.enable()
                     g.replay()
                     torch.cuda.synchronize(self.device)
                     ts = []

@@ -126,7 +126,14 @@ class _Graph:
         if None not in self.variants:   # the batch's own hints pick the variant (never the capture bound)
             key = self.runner.model.graph_variant_for(self.n_tokens, params)
             if key not in self.variants:
-                key = (1, False) if (1, False) in self.variants else next(iter(self.variants))
+                # the nearest captured variant: keep a valid uniform hint when only the lane count is missing
+                # (one lane + uniform skips the balanced partition's combine launch), then the plain graph
+                for alt in ((1, key[1]), (1, False)):
+                    if alt in self.variants:
+                        key = alt
+                        break
+                else:
+                    key = next(iter(self.variants))
         self.last_variant = key
         g, out = self.variants[key]
         g.replay()
