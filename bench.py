@@ -514,9 +514,12 @@ def main():
                     "per sequence, so kv_len grows by one per step from --seqlen")
     ap.add_argument("--lanes", type=int, default=-1, help="two half-batch lanes on two streams for pure-decode "
                     "batches of >= N tokens (0 = never; default: SLM_DECODE_LANES or the library's auto policy)")
-    ap.add_argument("--host", default="py", choices=["py", "cpp"], help="who composes the step: the Python mirror "
-                    "(decode.LlamaDecodeStep over ctypes) or the compiled C++ host step (csrc/shim/slm_llama_hip.cpp "
-                    "through _slm_shim.so); same kernels, same launch sequence -- under graph replay the same line")
+    ap.add_argument("--host", default="auto", choices=["auto", "py", "cpp"], help="who composes the step: the "
+                    "compiled C++ host step (csrc/shim/slm_llama_hip.cpp through _slm_shim.so; north_star: 'host code "
+                    "stays C++') or the Python mirror (decode.LlamaDecodeStep over ctypes); same kernels, same launch "
+                    "sequence.  auto (default): C++ on a single GPU with 4-bit weights -- the Python mirror's time is "
+                    "printed beside it as config.python_mirror_ms --, the mirror otherwise (TP ranks, --simulate-tp, "
+                    "8-bit weights: what the C++ step's bench plumbing does not cover)")
     ap.add_argument("--ragged", action="store_true", help="serving-shaped batch (SURVEY 8(d) config 2): "
                     "kv_len ~ U[seqlen/2, seqlen] per sequence (numpy default_rng(1)); not the BASELINE metric line")
     ap.add_argument("--simulate-tp", type=int, default=0, help="tuning aid: run rank 0's shard of a "
@@ -585,6 +588,17 @@ def main():
                 log=lambda m: print(f"[bench] lane 1: {m}", file=sys.stderr))
             if ar1 is not None:
                 custom_ar = [custom_ar, ar1]
+    host_note = None
+    if args.host == "auto":
+        args.host = "py"
+        if world == 1 and args.simulate_tp <= 1 and args.bits == 4:
+            try:
+                from scalellm_amd import cpp_host
+                cpp_host.load_shim()
+                args.host = "cpp"
+            except Exception as e:  # noqa: BLE001 -- no compiled shim here: say so and time the mirror
+                host_note = f"C++ host step unavailable ({type(e).__name__}: {str(e)[:120]}): Python mirror timed"
+                print(f"[bench] {host_note}", file=sys.stderr)
     model = LlamaDecodeStep(shape, bs, n_blocks, B, pa, quant_method=quant, group_size=128,
                             dtype=torch.bfloat16, device=device, seed=0, kv_fill=args.kv_fill,
                             custom_allreduce=custom_ar, gptq_sym=gptq_sym, bits=args.bits,
@@ -611,8 +625,8 @@ def main():
 
     static_tokens = tokens.clone()
 
-    def step():
-        if cpp_model is not None:
+    def step(use_cpp=True):
+        if cpp_model is not None and use_cpp:
             nxt = cpp_model.decode_step(static_tokens, positions, cpp_prm)
             model.last_lanes = cpp_model.last_lanes()
         else:
@@ -626,11 +640,21 @@ def main():
         torch.cuda.synchronize()
         torch.distributed.barrier()
     first_tokens = None
+    hosts_agree = None
     for i in range(max(args.warmup, 1)):
+        if i == 0 and cpp_model is not None:
+            # the same first step through the Python mirror (same inputs, same cache rows rewritten): the two hosts
+            # issue the same launches, so the greedy ids must be identical
+            step(use_cpp=False)
+            torch.cuda.synchronize()
+            py_tokens = static_tokens.clone()
+            static_tokens.copy_(tokens)
         step()
         if i == 0:  # the first step's greedy ids: a TP=N run must reproduce the TP=1 run's
             torch.cuda.synchronize()
             first_tokens = static_tokens[:16].tolist()
+            if cpp_model is not None:
+                hosts_agree = bool(torch.equal(py_tokens, static_tokens))
     torch.cuda.synchronize()
 
     def check_fused_reduce(where: str) -> None:
@@ -702,6 +726,28 @@ def main():
     check_fused_reduce("during the timed steps")
     ms_per_step = elapsed / args.steps * 1e3
     tok_s = bs * args.steps / elapsed
+    # the Python mirror beside the C++ host: the same step composed by decode.LlamaDecodeStep, captured and
+    # replayed the same way (config.python_mirror_ms)
+    py_ms = None
+    if cpp_model is not None:
+        try:
+            if graph is not None:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2):
+                    step(use_cpp=False)
+                run2 = g2.replay
+            else:
+                run2 = lambda: step(use_cpp=False)  # noqa: E731
+            for _ in range(max(args.warmup, 1)):
+                run2()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                run2()
+            torch.cuda.synchronize()
+            py_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] Python-mirror comparison run failed ({type(e).__name__}: {e})", file=sys.stderr)
 
     # ---- roofline of the dominant kernel (paged-attention decode), this rank's shard ----
     # (two-lane steps launch the attention once per HALF batch: that launch is the one measured)
@@ -791,8 +837,11 @@ def main():
                        "lane_policy": (dict(lane_probe, source="start-up probe (LlamaDecodeStep.probe_lanes)")
                                        if lane_probe else
                                        {"source": "forced" if model.lanes_min >= 0 else "constants (no probe ran)"}),
-                       "host": "c++ (slm::LlamaForCausalLMHip, _slm_shim.so)" if cpp_model is not None
-                               else "python mirror (decode.LlamaDecodeStep over ctypes)", "reduced_model": reduced,
+                       "host": "c++ (slm::LlamaForCausalLMHip, csrc/shim/slm_llama_hip.cpp in _slm_shim.so)"
+                               if cpp_model is not None else "python mirror (decode.LlamaDecodeStep over ctypes)",
+                       "python_mirror_ms": round(py_ms, 3) if py_ms is not None else None,
+                       "hosts_first_step_tokens_equal": hosts_agree, "host_note": host_note,
+                       "reduced_model": reduced,
                        "row_parallel_reduce": (None if world == 1 else
                                                "xgmi two-shot all-reduce fused with residual+rmsnorm "
                                                "(embedding gather and greedy sampling exchange through "

@@ -87,6 +87,7 @@ LlamaForCausalLMHip::LlamaForCausalLMHip(const LlamaArgs& args, const QuantArgs&
 
 void LlamaForCausalLMHip::load_state_dict(const StateDict& sd) {
   const int rank = parallel_args_.rank(), world = parallel_args_.world_size();
+  all_packed_ = false;   // (newly loaded tensors are repacked at their next use)
   // ParallelEmbedding: hidden-sharded (embedding.h:74-81); lm_head: column-parallel over the vocab
   auto t = sd.get_sharded_tensor("model.embed_tokens.weight", 1, rank, world);
   if (t.defined()) { embed_ = t.to(options_).contiguous(); embed_loaded_ = true; }
@@ -492,6 +493,15 @@ torch::Tensor LlamaForCausalLMHip::forward(const torch::Tensor& tokens, const to
     ln.pend_x = ln.resid; ln.pend_w = layers_[0].input_norm; ln.pend_splits = 0; ln.pend_residual = false;
   }
   if (lanes.size() == 2) {
+    // The layers repack their checkpoint tensors lazily, at the first forward (as the reference does inside its
+    // warm-up: weight_repacked_), on whatever stream is current.  With two lanes on two streams that would be a
+    // race on the FIRST two-lane step: lane 0 reaches a layer first and repacks it on its stream, lane 1 then
+    // finds it "packed" and reads it on the side stream with nothing ordering the two (round 6: NaN rows of
+    // lane 1 on the first step only).  So every layer is packed here, on the caller's stream, before the fork.
+    if (!all_packed_) {
+      for (auto& L : layers_) { L.qkv->packed(); L.o->packed(); L.gate_up->packed(); L.down->packed(); }
+      all_packed_ = true;
+    }
     run_two_lanes(lanes[0], lanes[1], kv_caches);
   } else {
     auto& ln = lanes[0];

@@ -151,6 +151,7 @@ class LlamaForCausalLMHip {
   // driven from one thread each need their own)
   std::optional<c10::hip::HIPStreamMasqueradingAsCUDA> side_stream_;
   int last_lanes_ = 1;
+  bool all_packed_ = false;   // every layer repacked before the first two-lane step (forward())
 };
 
 }  // namespace slm

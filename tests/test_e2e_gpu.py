@@ -186,6 +186,158 @@ def test_llama_two_lane_decode_step_and_cpp_host_match_oracle(host):
     assert agree >= 0.9 * total, f"greedy ids agree on only {agree}/{total} rows"
 
 
+def _all_row_check(h_got, lm_head_f32, ref_model, twin_model, inp, what):
+    """EVERY row of a step (not only each sequence's last token: a speculative-verify step samples at all
+    k + 1 positions, speculative_engine.cpp:162-185): final-norm hidden states and the logits they give, against
+    the fp32 oracle forward (<= 3e-2) and its bf16-storage twin (<= 1.5e-2).  Returns (#rows whose greedy id
+    equals the fp32 oracle's, #rows)."""
+    ref_model.forward(inp)
+    twin_model.forward(inp)
+    got = h_got.astype(np.float32) @ lm_head_f32
+    out = None
+    for model, tol, tag in ((ref_model, 3e-2, "fp32 oracle"), (twin_model, 1.5e-2, "bf16-storage twin")):
+        ref = model.trace["normed"].astype(np.float32) @ lm_head_f32
+        res = check_logits(got, ref, tol, f"{what} vs {tag} (all {len(got)} rows)")
+        out = out or res
+    return out[0], out[1]
+
+
+@pytest.mark.parametrize("host", ["py", "cpp"])
+def test_llama_config5_mixed_step_matches_oracle_on_every_row(host):
+    """Round 6 (round-5 review, parity hole 1): a BASELINE configs[4]-shaped step through the whole HIP stack
+    against the oracle twin DIRECTLY, on every query row -- one batch holding a prefill chunk over history
+    (q_len 19 on 16 cached tokens), speculative-verify rows (q_len = k + 1 = 5 over history: the pending token +
+    4 draft tokens, speculative_engine.cpp:162-239), plain decode rows (q_len 1) and a fresh prefill; then the
+    engine's bookkeeping after validation -- every verify sequence keeps a different number of accepted tokens
+    (1..5: its cache position moves by that much, the rejected draft rows stay in the cache as garbage past the
+    end, batch.cpp:304-350) -- and a second mixed step (verify again + decode) whose rows read that cache.
+    host = py: decode.LlamaDecodeStep; cpp: slm::LlamaForCausalLMHip (csrc/shim/slm_llama_hip.cpp)."""
+    from scalellm_amd.decode import LlamaDecodeStep, LlamaShape
+    shape, quant, gs, B = LlamaShape.tiny(), "awq", 128, 16
+    prompt_lens = [35, 21, 9, 40, 12, 30, 7, 26, 18, 5, 33, 14]
+    n = len(prompt_lens)
+    verify, K1 = [1, 2, 3, 4, 5, 6], 5          # sequences that run k + 1 = 5 rows per step
+    seqs = Sequences(prompt_lens, 24, B, shape.vocab, seed=23)
+    rng = np.random.default_rng(5)
+    model = LlamaDecodeStep(shape, 256, seqs.n_blocks, B, quant_method=quant, group_size=gs, dtype=torch.bfloat16,
+                            device=DEV, seed=9, keep_checkpoint=True)
+    model.reserve_workspaces(256, 128)
+    runner = None
+    if host == "cpp":
+        from scalellm_amd import cpp_host
+        cpp_host.load_shim()
+        runner = cpp_host.from_decode_step(model, B, 256, fused=True, lanes=64)
+    ref_model = _oracle_twin(model, quant, gs)
+    twin_model = _oracle_twin(model, quant, gs, storage="bf16")
+    lm_head = model.lm_head.float().cpu().numpy()
+
+    def run(new_lens, what):
+        inp = seqs.inputs(new_lens)
+        tokens, positions, params = _params(inp)
+        if host == "cpp":
+            from scalellm_amd import cpp_host
+            h = runner.forward(tokens, positions, cpp_host.cpp_params(params))
+        else:
+            model.forward(tokens, positions, params, return_logits=True)
+            h = model.buf["normed"][:tokens.numel()]
+        torch.cuda.synchronize()
+        h = h.float().cpu().numpy()
+        a, t = _all_row_check(h, lm_head, ref_model, twin_model, inp, f"config-5 step ({host}) {what}")
+        return inp, h @ lm_head, a, t
+
+    agree = total = 0
+    # step 0: prefill (sequence 0 only its first 16 tokens; the last sequence sits the step out)
+    first = list(prompt_lens)
+    first[0], first[-1] = 16, 0
+    inp, lg, a, t = run(first, "prefill")
+    agree, total = agree + a, total + t
+    seqs.advance(first)
+    last = inp["q_cu"][1:] - 1
+    seqs.feed(inp, lg[last].argmax(-1))
+    for rnd in range(2):
+        # the draft model's proposals: 4 tokens behind the pending one
+        for s in verify:
+            seqs.tokens[s] = seqs.tokens[s][:seqs.cached[s] + 1] + rng.integers(0, shape.vocab, size=K1 - 1).tolist()
+        new = [K1 if s in verify else 1 for s in range(n)]
+        if rnd == 0:
+            new[0], new[-1] = prompt_lens[0] - 16, prompt_lens[-1]    # chunk over history + a fresh prefill
+        inp, lg, a, t = run(new, f"mixed step {rnd} (q_lens {new})")
+        agree, total = agree + a, total + t
+        # validation: verify sequence s keeps `acc` of its 5 rows (1 = only the pending token ... 5 = all drafts);
+        # its next input token is the target model's choice at the last accepted row
+        row0 = {s: int(inp["q_cu"][i]) for i, s in enumerate(inp["rows"])}
+        adv = list(new)
+        for j, s in enumerate(verify):
+            acc = 1 + (j + rnd) % K1
+            adv[s] = acc
+            seqs.tokens[s] = seqs.tokens[s][:seqs.cached[s] + acc] + [int(lg[row0[s] + acc - 1].argmax())]
+        seqs.advance(adv)
+        for i, s in enumerate(inp["rows"]):
+            if s not in verify and seqs.cached[s] == len(seqs.tokens[s]):
+                seqs.tokens[s].append(int(lg[int(inp["q_cu"][i + 1]) - 1].argmax()))
+    print(f"[e2e] config-5 mixed steps ({host}): greedy ids equal on {agree}/{total} rows")
+    assert agree >= 0.97 * total, f"greedy ids agree on only {agree}/{total} rows"
+
+
+@pytest.mark.parametrize("nd", [1, 5])
+def test_llama_model_runner_replay_matches_oracle(nd):
+    """Round 6 (parity hole 1): the REPLAYED graph of ModelRunner (model_runner.cpp:112-211) against the oracle
+    twin directly -- until now a replay was only compared with the eager step.  nd = 5: every sequence brings
+    k + 1 = 5 verify rows (`num_decoding_tokens`, the reference's speculative graph); nd = 1: plain decode, and
+    with 72 sequences the replayed graph is the TWO-LANE variant."""
+    from scalellm_amd.decode import LlamaDecodeStep, LlamaShape
+    from scalellm_amd.model_runner import ModelRunner, ModelRunnerOptions
+    shape, quant, gs, B = LlamaShape.tiny(), "awq", 128, 16
+    bs = 72 if nd == 1 else 12
+    prompt_lens = [4 + (7 * i) % 29 for i in range(bs)]
+    seqs = Sequences(prompt_lens, 4 * nd + 2, B, shape.vocab, seed=31)
+    rng = np.random.default_rng(6)
+    model = LlamaDecodeStep(shape, max(sum(prompt_lens), bs * nd) + 8, seqs.n_blocks, B, quant_method=quant,
+                            group_size=gs, dtype=torch.bfloat16, device=DEV, seed=13, keep_checkpoint=True)
+    model.lanes_min = 64
+    model.reserve_workspaces(max(sum(prompt_lens), bs * nd) + 8, 128)
+    opts = ModelRunnerOptions(block_size=B, cuda_graph_max_seq_len=96, cuda_graph_batch_sizes=[bs],
+                              num_decoding_tokens=nd)
+    runner = ModelRunner(model, DEV, opts, return_logits=True)
+    ref_model = _oracle_twin(model, quant, gs)
+    twin_model = _oracle_twin(model, quant, gs, storage="bf16")
+    lm_head = model.lm_head.float().cpu().numpy()
+    # prefill eagerly (both sides), THEN capture (a capture runs the step: it must not touch live cache rows --
+    # the runner's static inputs name slot 0 of the unused block 0)
+    inp = seqs.inputs(prompt_lens)
+    tokens, positions, params = _params(inp)
+    lg = model.forward(tokens, positions, params, return_logits=True).float().cpu().numpy()
+    ref_model.forward(inp)
+    twin_model.forward(inp)
+    seqs.advance(prompt_lens)
+    seqs.feed(inp, lg.argmax(-1))
+    runner.capture_cuda_graphs(bs)
+    agree = total = 0
+    for step in range(3):
+        for s in range(bs):
+            seqs.tokens[s] = seqs.tokens[s][:seqs.cached[s] + 1] + rng.integers(0, shape.vocab, size=nd - 1).tolist()
+        inp = seqs.inputs([nd] * bs)
+        tokens, positions, params = _params(inp)
+        before = runner.num_graph_replayed
+        runner.forward(tokens, positions, params)
+        torch.cuda.synchronize()
+        assert runner.num_graph_replayed == before + 1
+        if nd == 1:
+            assert runner.graphs[bs].last_variant[0] == 2, runner.graphs[bs].last_variant   # the two-lane graph
+        h = model.buf["normed"][:bs * nd].float().cpu().numpy()
+        a, t = _all_row_check(h, lm_head, ref_model, twin_model, inp, f"ModelRunner replay nd={nd} step {step}")
+        agree, total = agree + a, total + t
+        lg = h @ lm_head
+        adv = []
+        for s in range(bs):   # keep 1..nd rows of every sequence; next token = the target's choice at the last kept row
+            acc = 1 + (s + step) % nd
+            adv.append(acc)
+            seqs.tokens[s] = seqs.tokens[s][:seqs.cached[s] + acc] + [int(lg[s * nd + acc - 1].argmax())]
+        seqs.advance(adv)
+    print(f"[e2e] ModelRunner replay nd={nd}: greedy ids equal on {agree}/{total} rows")
+    assert agree >= 0.97 * total, f"greedy ids agree on only {agree}/{total} rows"
+
+
 @pytest.mark.parametrize("wide", [False, True])
 def test_llama_one_layer_stage_by_stage_against_storage_twin(wide):
     """The tight pin behind the logits bounds: ONE decoder layer, prefill step, every buffer of the
