@@ -295,6 +295,14 @@ typedef struct slm_w4_gemm_args {
  * the MLP), minus one launch and the round trip of the [M, N] intermediate.  bias, if given, is in
  * packed column order.  Needs N % 64 == 0; cannot be combined with SLM_W4_DEFER_REDUCE. */
 #define SLM_W4_SILU_MUL 2
+/* flags: the call SHARES THE CHIP with kernels of another stream that must keep running next to it (the two
+ * half-batch decode lanes of DESIGN.md 3.6: one lane's GEMMs run under the other lane's attention stream).  A
+ * scheduling hint: the plan then avoids launch shapes whose workgroups cannot sit on a CU beside other waves --
+ * the two-row-tile K-sliced stream for 33 <= M <= 64 (512 threads x 236 VGPRs: alone it is the faster kernel,
+ * 89 vs 96 us per Llama-3-8B layer; beside an attention stream its workgroups wait for whole CUs, 14.2 -> 21.5 ms
+ * at bs 128).  Results are correct either way; the SAME flag must be passed to the workspace / deferred-splits
+ * queries (they describe the plan the call will take). */
+#define SLM_W4_SHARES_CHIP 4
 
 SLM_API size_t slm_w4a16_gemm_workspace_bytes(const slm_w4_gemm_args* a);
 /* number of partial slabs the call will leave in the workspace (>= 2), or 0 when it writes c as usual */

@@ -55,6 +55,7 @@ class W4GemmArgs(C.Structure):
 
 SLM_W4_DEFER_REDUCE = 1
 SLM_W4_SILU_MUL = 2
+SLM_W4_SHARES_CHIP = 4
 
 
 class W4NormPrologue(C.Structure):

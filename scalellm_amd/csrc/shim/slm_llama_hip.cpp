@@ -317,7 +317,7 @@ void LlamaForCausalLMHip::pre_attn(Lane& ln, size_t li, std::vector<KVCache>& kv
   auto& w = L.qkv->packed();
   // the qkv projection is column-parallel: its split-K slabs can go to the RoPE + append kernel on
   // any world size
-  const int flags = SLM_W4_DEFER_REDUCE;
+  const int flags = SLM_W4_DEFER_REDUCE | chip_flag_;
   const size_t need = w.workspace_bytes(n, flags);
   ln.qkv_splits = w.forward_into(ln.normed, ln.qkv, flags, deferred(ln.idx, 0, need));
   const int64_t nq = n_heads_ * D, nkv = n_kv_heads_ * D;
@@ -387,7 +387,7 @@ void LlamaForCausalLMHip::post_attn(Lane& ln, size_t li) {
   auto a2 = ln.attn.view({n, -1});
   {
     auto& w = L.o->packed();
-    const int flags = single ? SLM_W4_DEFER_REDUCE : 0;
+    const int flags = (single ? SLM_W4_DEFER_REDUCE : 0) | chip_flag_;
     const size_t need = w.workspace_bytes(n, flags);
     const int splits = w.forward_into(a2, ln.o_buf, flags, single ? deferred(ln.idx, 0, need) : scratch(ln.idx, need));
     reduce_add_norm(ln, 0, ln.o_buf, L.post_norm, splits, 0);
@@ -395,17 +395,17 @@ void LlamaForCausalLMHip::post_attn(Lane& ln, size_t li) {
   {
     auto& w = L.gate_up->packed();
     if (w.paired()) {
-      const size_t need = w.workspace_bytes(n, SLM_W4_SILU_MUL);
-      w.forward_into(ln.normed, ln.act, SLM_W4_SILU_MUL, scratch(ln.idx, need));
+      const size_t need = w.workspace_bytes(n, SLM_W4_SILU_MUL | chip_flag_);
+      w.forward_into(ln.normed, ln.act, SLM_W4_SILU_MUL | chip_flag_, scratch(ln.idx, need));
     } else {
-      const size_t need = w.workspace_bytes(n, 0);
-      w.forward_into(ln.normed, ln.gate_up, 0, scratch(ln.idx, need));
+      const size_t need = w.workspace_bytes(n, chip_flag_);
+      w.forward_into(ln.normed, ln.gate_up, chip_flag_, scratch(ln.idx, need));
       llm::kernel::silu_and_mul(ln.act, ln.gate_up);
     }
   }
   {
     auto& w = L.down->packed();
-    const int flags = single ? SLM_W4_DEFER_REDUCE : 0;
+    const int flags = (single ? SLM_W4_DEFER_REDUCE : 0) | chip_flag_;
     const size_t need = w.workspace_bytes(n, flags);
     const int splits = w.forward_into(ln.act, ln.down_buf, flags, single ? deferred(ln.idx, 0, need) : scratch(ln.idx, need));
     const auto& nxt = li + 1 < layers_.size() ? layers_[li + 1].input_norm : final_norm_;
@@ -447,6 +447,8 @@ void LlamaForCausalLMHip::run_two_lanes(Lane& l0, Lane& l1, std::vector<KVCache>
     return events.back().get();
   };
   record(main)->block(side);  // fork
+  // the lanes' GEMMs run beside the other lane's attention stream: the plan keeps to workgroups that fit there
+  struct ChipFlag { int& f; explicit ChipFlag(int& x) : f(x) { f = SLM_W4_SHARES_CHIP; } ~ChipFlag() { f = 0; } } chip(chip_flag_);
   Lane* lanes[2] = {&l0, &l1};
   const Stream streams[2] = {main, side};
   const size_t n = layers_.size();

@@ -151,6 +151,7 @@ class LlamaForCausalLMHip {
   // driven from one thread each need their own)
   std::optional<c10::hip::HIPStreamMasqueradingAsCUDA> side_stream_;
   int last_lanes_ = 1;
+  int chip_flag_ = 0;          // SLM_W4_SHARES_CHIP while a two-lane step issues its GEMMs, else 0
   bool all_packed_ = false;   // every layer repacked before the first two-lane step (forward())
 };
 

@@ -37,7 +37,7 @@ enum TuneKey : int {
   TUNE_W4_KS_NW,          // SLM_W4_KS_NW          forced waves per workgroup (4/8/16)
   TUNE_W4_KS_TPW,         // SLM_W4_KS_TPW         forced column tiles per workgroup
   TUNE_W4_KS_DBG,         // SLM_W4_KS_DBG         probe bits (1 = no activation loads, 2 = no weight loads): WRONG results
-  TUNE_W4_KS_MT2,         // SLM_W4_KS_MT2         1 = 33 <= M <= 64 on the two-row-tile K-sliced stream (K <= 4096), 2 = any K; default 0
+  TUNE_W4_KS_MT2,         // SLM_W4_KS_MT2         1 = 33 <= M <= 64 on the two-row-tile K-sliced stream (K <= 4096), 2 = any K, 0 = never; default: on unless the call carries SLM_W4_SHARES_CHIP
   TUNE_W4_M128,           // SLM_W4_M128           w4_m128.hip at 65 <= M <= 128: 1 = always, 0 = never (default: K >= 8192)
   TUNE_W4_M128_WD,        // SLM_W4_M128_WD        weight ring depth of w4_m128.hip in 64-deep chunks (2 / 4)
   TUNE_W4_M128_SPLITS,    // SLM_W4_M128_SPLITS    workgroups w4_m128.hip's split-K aims at (default 512 = two per CU)

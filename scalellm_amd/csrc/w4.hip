@@ -532,7 +532,7 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   if (a->M < 0 || a->K <= 0 || a->N <= 0) return SLM_ERR_INVALID_ARG;
   if (a->dtype != SLM_F16 && a->dtype != SLM_BF16) return SLM_ERR_UNSUPPORTED;
   if (a->K % W4_KC || a->N % 32) return SLM_ERR_UNSUPPORTED;  // reference: K%128, N%64
-  if (a->flags & ~(SLM_W4_DEFER_REDUCE | SLM_W4_SILU_MUL)) return SLM_ERR_INVALID_ARG;
+  if (a->flags & ~(SLM_W4_DEFER_REDUCE | SLM_W4_SILU_MUL | SLM_W4_SHARES_CHIP)) return SLM_ERR_INVALID_ARG;
   if (a->flags & SLM_W4_SILU_MUL) {
     if (a->flags & SLM_W4_DEFER_REDUCE) return SLM_ERR_INVALID_ARG;
     if (a->N % 64) return SLM_ERR_UNSUPPORTED;
@@ -696,18 +696,23 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
     }
   }
   pl->ks_mt = 1;
-  // 33 <= M <= 64 (round 4, OPT-IN: SLM_W4_KS_MT2=1): the K-sliced stream with TWO row tiles -- every
+  // 33 <= M <= 64 (round 4; the default outside the two-lane steps since round 6): the K-sliced stream with TWO row tiles -- every
   // weight word unpacked once for two MFMAs.  One chunk of K per wave (the activations of both row
   // tiles fill the registers), 8 waves: a workgroup covers 1024 of K, the rest is split across
   // workgroups (fp32 slabs, summed by the consumer under SLM_W4_DEFER_REDUCE or by the reduce kernel).
   // Measured (profiles/r04_ks_mt2.jsonl, M = 64 stand-alone): qkv 19.5 -> 17.6 us, gate_up 40.4 -> 36.6,
   // o 15.8 -> 15.6, down 26.3 -> 36.1 (14 slabs: excluded below); the bs = 64 decode step 9.07 -> 8.93 ms.
-  // NOT the default: under the two-lane decode step (decode.py) its 512-thread, 236-VGPR workgroups
+  // NOT under the two-lane decode step (decode.py; SLM_W4_SHARES_CHIP): there its 512-thread, 236-VGPR workgroups
   // cannot share a CU with the other lane's attention waves and wait for them instead -- bs = 128
   // (two lanes of 64 rows) 14.2 -> 21.5 ms -- and the stand-alone gain is small because A (512 KB at
   // M = 64, K = 4096) cannot stay on one CU: either K is split over CUs (slab traffic, this kernel) or
   // A is re-streamed per column tile (the general kernel); the step from M = 32 stays.
-  if (tune_get(TUNE_W4_KS, 1) != 0 && tune_get(TUNE_W4_KS_MT2, 0) != 0 && a->M > 32 && a->M <= 64 && !pl->gemv &&
+  // Round 6: ON by default where the caller does not say the call shares the chip (SLM_W4_SHARES_CHIP, set by
+  // the two-lane decode steps): M = 33 / 48 / 64 layer chain 96 / 97 / 101 -> 89 / 90 / 93 us, bs = 64 step
+  // 9.17 -> 8.95 ms (profiles/r06_ks_mt2_default.jsonl).  SLM_W4_KS_MT2 = 0 never, 1 / 2 always (2: any split).
+  const int mt2_knob = tune_get(TUNE_W4_KS_MT2, -1);
+  const bool mt2_on = mt2_knob > 0 || (mt2_knob < 0 && !(a->flags & SLM_W4_SHARES_CHIP));
+  if (tune_get(TUNE_W4_KS, 1) != 0 && mt2_on && a->M > 32 && a->M <= 64 && !pl->gemv &&
       a->K * a->N / 2 < ((int64_t)1 << 32) && (a->K / gs) * a->N * 4 < ((int64_t)1 << 32) &&
       ((a->M - 1) * a->lda + a->K) * 2 < ((int64_t)1 << 31) &&
       ((a->M - 1) * a->ldc + a->N) * 2 < ((int64_t)1 << 31) && a->M * a->N * 4 < ((int64_t)1 << 31) &&
@@ -726,7 +731,7 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
     // deep K (down_proj: 14 slabs of fp32 partials) loses to the general kernel's 8-way split with
     // wider tiles (M = 64: 36.1 vs 26.3 us); up to 4 slabs it wins or ties (qkv 17.6 vs 19.5, o 15.6 vs
     // 15.8, gate_up 36.6 vs 40.4 us; profiles/r04_ks_mt2.jsonl).  SLM_W4_KS_MT2=2 lifts the bound (tests).
-    const int max_split = tune_get(TUNE_W4_KS_MT2, 0) >= 2 ? 16 : 4;
+    const int max_split = mt2_knob >= 2 ? 16 : 4;
     if (ksplit <= max_split && (forced_split <= 0 || ksplit == forced_split)) {
       pl->ks = 1;
       pl->ks_mt = 2;

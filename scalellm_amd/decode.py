@@ -611,6 +611,7 @@ class LlamaDecodeStep:
             st = contextlib.ExitStack()
             st.enter_context(torch.cuda.stream(ln.stream))
             st.enter_context(kernels.workspace_lane(ln.idx))
+            st.enter_context(kernels.shared_chip())   # (SLM_W4_SHARES_CHIP: the lanes' GEMMs run beside an attention stream)
             return st
         n = len(self.layers)
         for ln in (l0, l1):

@@ -119,6 +119,22 @@ def workspace_lane(lane: int):
         _lane_tls.lane = prev
 
 
+@contextlib.contextmanager
+def shared_chip(on: bool = True):
+    """GEMM calls issued inside run NEXT TO another stream's kernels (the two half-batch decode lanes): they carry
+    SLM_W4_SHARES_CHIP, so that the plan keeps to launch shapes whose workgroups fit on a CU beside other waves."""
+    prev = getattr(_lane_tls, "shared", False)
+    _lane_tls.shared = bool(on)
+    try:
+        yield
+    finally:
+        _lane_tls.shared = prev
+
+
+def _chip_flag() -> int:
+    return _lib.SLM_W4_SHARES_CHIP if getattr(_lane_tls, "shared", False) else 0
+
+
 def _grow(table, nbytes: int, dev: torch.device, what: str) -> torch.Tensor:
     key = _dev_key(dev)
     ws = table.get(key)
@@ -690,14 +706,16 @@ def gptq_gemm(a: torch.Tensor, packed: PackedW4, c: torch.Tensor,
         npro.residual_out = norm.residual_out.data_ptr() if norm.residual_out is not None else None
         npro.weight = norm.weight.data_ptr()
         npro.normed_out = norm.normed_out.data_ptr() if norm.normed_out is not None else None
+    chip = _chip_flag()
+    g.flags = chip
     if silu_mul:
-        g.flags = _lib.SLM_W4_SILU_MUL
+        g.flags = _lib.SLM_W4_SILU_MUL | chip
     deferred = 0
     if defer_reduce:
-        g.flags = _lib.SLM_W4_DEFER_REDUCE
+        g.flags = _lib.SLM_W4_DEFER_REDUCE | chip
         deferred = L.slm_w4a16_gemm_deferred_splits(C.byref(g))
         if not deferred:
-            g.flags = 0
+            g.flags = chip
     need = L.slm_w4a16_gemm_workspace_bytes(C.byref(g))
     ws = None
     if need:

@@ -73,8 +73,12 @@ def test_two_lanes_equal_the_half_batches_bit_for_bit_eager_and_replayed(bs, cha
     h = model._lane_split(bs, params, None)
     assert 0 < h < bs and h % 32 == 0
     model.lanes_min = 0
+    from scalellm_amd import kernels
     for r0, r1 in ((0, h), (h, bs)):
-        half = model.forward(tokens[r0:r1], positions[r0:r1], _slice_params(params, r0, r1), return_logits=True)
+        # (the lanes' GEMMs carry SLM_W4_SHARES_CHIP -- the plan hint of a call that runs beside another stream --
+        # so the half batch alone is run with the same hint: same plans, same bits)
+        with kernels.shared_chip():
+            half = model.forward(tokens[r0:r1], positions[r0:r1], _slice_params(params, r0, r1), return_logits=True)
         torch.cuda.synchronize()
         assert torch.equal(got[r0:r1], half), f"lane rows [{r0}, {r1}): max |diff| " \
                                               f"{(got[r0:r1].float() - half.float()).abs().max().item()}"
@@ -200,8 +204,10 @@ def test_two_lanes_on_a_tensor_parallel_rank_equal_the_half_batches():
     h = model._lane_split(bs, params, None)
     restore()
     model.lanes_min = 0
+    from scalellm_amd import kernels
     for r0, r1 in ((0, h), (h, bs)):
-        half = model.forward(tokens[r0:r1], positions[r0:r1], _slice_params(params, r0, r1), return_logits=True)
+        with kernels.shared_chip():
+            half = model.forward(tokens[r0:r1], positions[r0:r1], _slice_params(params, r0, r1), return_logits=True)
         torch.cuda.synchronize()
         assert model.last_lanes == 1
         assert torch.equal(got[r0:r1], half), (r0, r1, float((got[r0:r1].float() - half.float()).abs().max()))

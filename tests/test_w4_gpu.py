@@ -579,3 +579,37 @@ def test_w4_rejects_bad_shapes():
     with pytest.raises(SlmError):  # dtype mismatch with the prepacked scales
         kernels.gptq_gemm(torch.zeros(4, 128, device=DEV, dtype=torch.bfloat16), packed,
                           torch.zeros(4, 64, device=DEV, dtype=torch.bfloat16))
+
+
+# ---- round 6: SLM_W4_SHARES_CHIP (the two-row-tile K-sliced stream is the default for 33 <= M <= 64 unless the call shares the chip)
+@pytest.mark.parametrize("M,K,N", [(33, 4096, 6144), (48, 4096, 4096), (64, 4096, 28672), (64, 14336, 4096)])
+def test_shares_chip_flag_only_changes_the_plan(M, K, N):
+    """Alone, 33 <= M <= 64 runs on the two-row-tile K-sliced stream (up to 4 slabs); with SLM_W4_SHARES_CHIP (what
+    the two decode lanes pass) the call keeps the general kernel.  Both are right against the oracle, each repeats
+    bit-identically, and the flag reaches the deferred-splits query."""
+    from scalellm_amd import kernels
+    case = helpers.make_quant_case(M + K, K, N, 128, "awq", "bf16")
+    packed = _pack(case, "bf16")
+    g = torch.Generator(device=DEV).manual_seed(K + M)
+    a = torch.randn(M, K, device=DEV, dtype=torch.bfloat16, generator=g)
+    ref = oracle.gemm_f32(a.float().cpu().numpy(), _oracle_w(case))
+    outs = {}
+    for shared in (False, True):
+        with kernels.shared_chip(shared):
+            c1 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+            c2 = torch.full_like(c1, float("nan"))
+            kernels.gptq_gemm(a, packed, c1)
+            kernels.gptq_gemm(a, packed, c2)
+            torch.cuda.synchronize()
+            assert torch.equal(c1, c2)
+            assert _rel_err(c1.float().cpu().numpy(), ref) < GEMM_TOL["bf16"]
+            outs[shared] = c1
+    with kernels.tuning(SLM_W4_KS_MT2=0):       # the knob's "never" == the flag's plan
+        c0 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        kernels.gptq_gemm(a, packed, c0)
+        torch.cuda.synchronize()
+    assert torch.equal(c0, outs[True])
+    if K <= 4096:                                # (<= 4 slabs: the two-row-tile stream is taken alone -- other bits)
+        assert not torch.equal(outs[False], outs[True])
+    else:
+        assert torch.equal(outs[False], outs[True])
