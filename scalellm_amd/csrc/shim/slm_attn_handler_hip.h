@@ -22,6 +22,8 @@
 #pragma once
 #include <torch/torch.h>
 
+#include "slm_torch_shim.h"  // slm::uniform_kv_hint
+
 #include <memory>
 #include <tuple>
 
@@ -62,6 +64,9 @@ struct InputParameters {
   torch::Tensor cu_block_lens;    // [n_seq + 1] int32
   // extension (not in models/parameters.h): cu_seq_lens.back() as Batch::prepare_model_input has it on the
   // host (batch.cpp:137), 0 = unknown -- a scheduling hint like the two maxima (slm_attn_args::total_kv_len)
+  // 0 = unknown: derived from host-known sizes where they settle it (slm::uniform_kv_hint, slm_torch_shim.h: what
+  // an unchanged engine gets); < 0 = known NOT to be uniform (a graph captured over padded static buffers, the
+  // half of a ragged batch)
   int64_t kv_total_len = 0;
 };
 

@@ -258,7 +258,7 @@ std::vector<LlamaForCausalLMHip::Lane> LlamaForCausalLMHip::make_lanes(int64_t T
       ln.params.new_cache_slots = p.new_cache_slots.narrow(0, r0, n);
       ln.params.cu_block_lens = p.cu_block_lens.narrow(0, r0, n + 1);
       // the halves of a uniform batch are uniform (the one case the hint distinguishes); else unknown
-      ln.params.kv_total_len = p.kv_total_len == T * static_cast<int64_t>(p.kv_max_seq_len) ? n * p.kv_max_seq_len : 0;
+      ln.params.kv_total_len = p.kv_total_len == T * static_cast<int64_t>(p.kv_max_seq_len) ? n * p.kv_max_seq_len : -1;
     }
     ln.resid = resid_.narrow(0, r0, n); ln.normed = normed_.narrow(0, r0, n);
     ln.qkv = qkv_.narrow(0, r0, n); ln.attn = attn_.narrow(0, r0, n);
@@ -488,7 +488,18 @@ torch::Tensor LlamaForCausalLMHip::forward(const torch::Tensor& tokens, const to
     x = torch::cat(parts, -1);
   }
   resid.copy_(x);
-  auto lanes = make_lanes(T, positions, input_params);
+  // an engine that fills no hint (the reference's Batch::prepare_model_input): the sizes it hands over settle the
+  // uniform case for the whole step, lanes included (slm::uniform_kv_hint).  Not under capture: the captured
+  // parameters are padded static buffers and bounds.
+  InputParameters hinted;
+  const InputParameters* prm = &input_params;
+  if (input_params.kv_total_len == 0 && !capturing()) {
+    const int64_t total = uniform_kv_hint(0, input_params.q_cu_seq_lens.size(0) - 1, input_params.q_max_seq_len,
+                                          input_params.kv_max_seq_len, input_params.block_tables.numel(),
+                                          kv_caches.empty() ? 0 : kv_caches[0].block_size());
+    if (total > 0) { hinted = input_params; hinted.kv_total_len = total; prm = &hinted; }
+  }
+  auto lanes = make_lanes(T, positions, *prm);
   last_lanes_ = static_cast<int>(lanes.size());
   for (auto& ln : lanes) {  // the first input norm: no residual yet
     ln.norm_pending = true;

@@ -112,6 +112,15 @@ void paged_kv_varlen_mha(torch::Tensor& out, const torch::Tensor& query,
   a.sliding_window = sliding_window;
   a.num_splits = 0;
   if (a.n_tokens == 0 || a.batch_size == 0) return;
+  // The reference's signature (attn_api.h:12-27) has no total-length argument and its engine fills none: what the
+  // SIZES it hands over settle is derived here -- a pure-decode batch whose flattened block table holds exactly
+  // batch * ceil(max_kv_len / block_size) entries is uniform to within one block (slm::uniform_kv_hint), and the
+  // plan then skips the balanced partition and its combine launch.  Not under stream capture: a captured call
+  // sees padded static buffers and bounds (model_runner.cpp:88-90, 196-200), not a batch.
+  if (c10::hip::currentStreamCaptureStatusMayInitCtx() == c10::hip::CaptureStatus::None) {
+    const int64_t total = slm::uniform_kv_hint(0, a.batch_size, max_q_len, max_kv_len, block_table.numel(), block_size);
+    if (total > 0 && total < (int64_t(1) << 31)) a.total_kv_len = static_cast<int32_t>(total);
+  }
   const size_t need = slm_paged_kv_varlen_mha_workspace_bytes(&a);
   torch::Tensor ws;
   if (need > 0) {

@@ -116,6 +116,20 @@ void awq_repack(const torch::Tensor& q_weight,  // (k, n/8)
 
 namespace slm {
 
+// The total_kv_len the attention plan is given (slm_attn_args::total_kv_len), from what the HOST knows -- same rule
+// as layers.uniform_kv_hint: the caller's value when > 0; "not uniform" (< 0) -> 0; unknown (0): a pure-decode batch
+// whose flattened block table (batch.cpp:206-209) has exactly n_seqs * ceil(kv_max_seq_len / block_size) entries
+// holds more than kv_max_seq_len - block_size tokens in EVERY sequence -- as uniform as the plan needs -- and is
+// reported as n_seqs * kv_max_seq_len.  Anything else: 0 (the balanced partition, right for every batch).
+inline int64_t uniform_kv_hint(int64_t kv_total_len, int64_t n_seqs, int64_t q_max_seq_len, int64_t kv_max_seq_len,
+                               int64_t block_table_len, int64_t block_size) {
+  if (kv_total_len > 0) return kv_total_len;
+  if (kv_total_len < 0 || n_seqs <= 0 || q_max_seq_len > 1 || kv_max_seq_len <= 0 || block_size <= 0) return 0;
+  const int64_t blocks = (kv_max_seq_len + block_size - 1) / block_size;
+  return block_table_len == n_seqs * blocks ? n_seqs * kv_max_seq_len : 0;
+}
+
+
 // int4 linear in the library's packed layout.  Built once from CHECKPOINT-format tensors (the
 // same tensors the reference's load_state_dict collects), then forward() = one GEMM launch.
 // entries of the fused {scale, zero} table cache behind marlin::gptq_gemm (tests: the cache is swept

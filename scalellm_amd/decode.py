@@ -13,6 +13,7 @@ The step is hipGraph-capturable: static buffers, no host sync, no allocation aft
 from __future__ import annotations
 
 import contextlib
+import dataclasses
 import os
 
 from dataclasses import dataclass
@@ -21,7 +22,7 @@ from typing import List, Optional
 import torch
 
 from . import kernels
-from .layers import (Attention, ColumnParallelQLinear, HipAttnHandler, InputParameters, KVCache,
+from .layers import (Attention, ColumnParallelQLinear, HipAttnHandler, InputParameters, KVCache, uniform_kv_hint,
                      QuantArgs, RowParallelQLinear)
 from .model_parallel import ParallelArgs
 
@@ -385,8 +386,10 @@ class LlamaDecodeStep:
         n_seqs = params.q_cu_seq_lens.numel() - 1
         ar = self.custom_ar if self.pa.world_size > 1 else None
         lanes = 2 if self._lane_split(n_tokens, params, ar) > 0 else 1
-        uniform = (params.q_max_seq_len == 1 and n_tokens == n_seqs and
-                   getattr(params, "kv_total_len", 0) == n_seqs * params.kv_max_seq_len)
+        # (the caller's hint, or what the sizes of an unchanged engine's parameters settle: layers.uniform_kv_hint)
+        total = uniform_kv_hint(getattr(params, "kv_total_len", 0), n_seqs, params.q_max_seq_len,
+                                params.kv_max_seq_len, params.block_tables.numel(), self.block_size)
+        uniform = (params.q_max_seq_len == 1 and n_tokens == n_seqs and total == n_seqs * params.kv_max_seq_len)
         return lanes, bool(uniform)
 
     def probe_lanes(self, n_tokens: int, kv_len: int, n_layers: int = 8, reps: int = 3):
@@ -495,7 +498,7 @@ class LlamaDecodeStep:
                     # every sequence at the maximum <=> the whole batch is: the halves of a uniform batch
                     # are uniform (the only case the hint distinguishes); otherwise unknown
                     kv_total_len=(r1 - r0) * params.kv_max_seq_len
-                    if getattr(params, "kv_total_len", 0) == T * params.kv_max_seq_len else 0)
+                    if getattr(params, "kv_total_len", 0) == T * params.kv_max_seq_len else -1)
             ln.resid, ln.normed = b["resid"][r0:r1], b["normed"][r0:r1]
             ln.alt = b["resid_alt"][:T] if fold else None
             ln.qkv, ln.attn, ln.act = b["qkv"][r0:r1], b["attn"][r0:r1], b["act"][r0:r1]
@@ -666,6 +669,13 @@ class LlamaDecodeStep:
         """tokens/positions [T] int32 -> next-token ids [n_seqs] (greedy), last token per sequence."""
         s, b, pa = self.shape, self.buf, self.pa
         T = tokens.numel()
+        if getattr(params, "kv_total_len", 0) == 0 and not torch.cuda.is_current_stream_capturing():
+            # an engine that fills no hint (the reference's Batch::prepare_model_input): the sizes it hands
+            # over settle the uniform case for the whole step -- lanes included (layers.uniform_kv_hint)
+            total = uniform_kv_hint(0, params.q_cu_seq_lens.numel() - 1, params.q_max_seq_len,
+                                    params.kv_max_seq_len, params.block_tables.numel(), self.block_size)
+            if total:
+                params = dataclasses.replace(params, kv_total_len=total)
         resid, normed = b["resid"][:T], b["normed"][:T]
         ar = self.custom_ar if pa.world_size > 1 else None
         x = self.embed[tokens.long()]

@@ -40,9 +40,30 @@ class InputParameters:
     q_max_seq_len: int = 0
     kv_max_seq_len: int = 0
     # extension (not in models/parameters.h): cu_seq_lens.back() as Batch::prepare_model_input has it on
-    # the host (batch.cpp:137); 0 = unknown.  A scheduling hint like the two maxima above: lets the
-    # attention plan recognise a uniform batch (kernels.paged_kv_varlen_mha, total_kv_len)
+    # the host (batch.cpp:137).  A scheduling hint like the two maxima above: lets the attention plan recognise
+    # a uniform batch (kernels.paged_kv_varlen_mha, total_kv_len).  0 = unknown: derived from the host-known
+    # SIZES where they settle it (uniform_kv_hint below -- what an unchanged engine gets); < 0 = known NOT to
+    # be uniform (no derivation: a graph captured over padded static buffers, the half of a ragged batch)
     kv_total_len: int = 0
+
+
+def uniform_kv_hint(kv_total_len: int, n_seqs: int, q_max_seq_len: int, kv_max_seq_len: int,
+                    block_table_len: int, block_size: int) -> int:
+    """The total_kv_len the attention plan is given (slm_attn_args::total_kv_len), from what the HOST knows.
+
+    The caller's own value wins (> 0; < 0 means "not uniform": 0 is returned).  Unknown (0): the reference's
+    InputParameters (models/parameters.h:11-56) carries the two maxima and the flattened block table
+    (batch.cpp:206-209), whose LENGTH the host has: a pure-decode batch whose table holds exactly
+    n_seqs * ceil(kv_max_seq_len / block_size) entries has, in EVERY sequence, more than kv_max_seq_len -
+    block_size tokens -- as uniform as the plan needs (one workgroup per sequence and head group is then the
+    balanced partition already) -- and is reported as n_seqs * kv_max_seq_len.  Anything else: 0 (the balanced
+    partition, right for every batch).  Like every hint of the call it only shapes the launch."""
+    if kv_total_len > 0:
+        return int(kv_total_len)
+    if kv_total_len < 0 or n_seqs <= 0 or q_max_seq_len > 1 or kv_max_seq_len <= 0 or block_size <= 0:
+        return 0
+    blocks = (kv_max_seq_len + block_size - 1) // block_size
+    return n_seqs * kv_max_seq_len if block_table_len == n_seqs * blocks else 0
 
 
 class KVCache:
@@ -112,13 +133,20 @@ class HipAttnHandler:
     def batch_decode(self, query, kv_cache: KVCache, input_params: InputParameters,
                      sliding_window: int, output: torch.Tensor, phase: int = 0) -> None:
         kc, vc = kv_cache.get_kv_cache()
+        total = getattr(input_params, "kv_total_len", 0)
+        if total == 0 and not torch.cuda.is_current_stream_capturing():
+            # (an unchanged engine fills no hint: the sizes it hands over settle the uniform case.  Not under
+            # capture: a captured call sees padded static buffers and bounds, not a batch)
+            total = uniform_kv_hint(0, input_params.q_cu_seq_lens.numel() - 1, input_params.q_max_seq_len,
+                                    input_params.kv_max_seq_len, input_params.block_tables.numel(),
+                                    kv_cache.block_size())
         kernels.paged_kv_varlen_mha(output, query, kc, vc, input_params.q_cu_seq_lens,
                                     input_params.kv_cu_seq_lens, input_params.block_tables,
                                     input_params.cu_block_lens, self.alibi_slopes,
                                     kv_cache.block_size(), input_params.q_max_seq_len,
                                     input_params.kv_max_seq_len, self.sm_scale,
                                     self.logits_soft_cap, sliding_window,
-                                    total_kv_len=getattr(input_params, "kv_total_len", 0), phase=phase)
+                                    total_kv_len=total, phase=phase)
 
 
 class Attention:

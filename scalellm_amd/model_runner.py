@@ -76,8 +76,10 @@ class _Graph:
     def _params_for(self, variant) -> InputParameters:
         """The capture-time parameters of a variant: the uniform ones claim every sequence at the bound."""
         import dataclasses
-        if variant is None or not variant[1]:
+        if variant is None:
             return self.params
+        if not variant[1]:   # (known not to be uniform: nothing is derived from the padded static block table)
+            return dataclasses.replace(self.params, kv_total_len=-1)
         return dataclasses.replace(self.params, kv_total_len=self.batch_size * self.params.kv_max_seq_len)
 
     def capture(self, fn: Callable) -> None:

@@ -153,9 +153,14 @@ def test_model_runner_picks_the_graph_variant_from_the_replayed_batch():
              ("uniform", [300] * bs, 64, (2, True)),
              ("uniform, lanes off for this batch", [300] * bs, 0, (1, True)),
              ("ragged, lanes off", [int(x) for x in rng.integers(1, max_len, size=bs)], 0, (1, False))]
+    # round 6: an unchanged engine fills no kv_total_len -- the sizes of its parameters settle the uniform case
+    # (layers.uniform_kv_hint: the flattened block table has exactly bs * ceil(kv_max / block) entries)
+    cases += [("uniform, no hint from the engine", [300] * bs, 64, (2, True)),
+              ("uniform to within a block, no hint", [290] * (bs - 1) + [300], 64, (2, True)),
+              ("ragged, no hint", [int(x) for x in rng.integers(1, max_len, size=bs)], 64, (2, False))]
     for name, kv, lanes_min, variant in cases:
         t, p, prm = _batch(rng, bs, 1, kv, B, n_blocks, shape.vocab)
-        prm = dataclasses.replace(prm, kv_total_len=sum(kv))
+        prm = dataclasses.replace(prm, kv_total_len=0 if "no hint" in name else sum(kv))
         model.lanes_min = lanes_min
         restore()
         out = runner.forward(t, p, prm).clone()

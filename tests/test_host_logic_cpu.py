@@ -253,3 +253,40 @@ def test_lane_policy_measurements_override_the_constants():
     finally:
         L.slm_decode_lane_policy_clear()
     assert two_lane_split(s70, 64, 8, 1, -1, 128, 128, 1, 4096) == 0
+
+
+def test_uniform_kv_hint_from_host_known_sizes():
+    """Round 6 (round-5 review, missing 6): an unchanged engine fills no kv_total_len.  What the SIZES of the
+    reference's own InputParameters settle is derived: a pure-decode batch whose flattened block table has exactly
+    n_seqs * ceil(kv_max_seq_len / block_size) entries is uniform to within one block.  The engine-format builders
+    of this repo (batch.cpp:137-209 mirrors) are the fixture."""
+    from scalellm_amd.decode import make_batch_inputs
+    from scalellm_amd.layers import uniform_kv_hint
+
+    def hint(kv_lens, block, q_lens=None, given=0):
+        q_lens = q_lens or [1] * len(kv_lens)
+        _, _, p, _ = make_batch_inputs(q_lens, kv_lens, block, "cpu", seed=1)
+        return uniform_kv_hint(given, len(kv_lens), max(q_lens), max(kv_lens), p.block_tables.numel(), block)
+
+    assert hint([4096] * 256, 16) == 256 * 4096
+    assert hint([4096] * 256, 8) == 256 * 4096
+    assert hint([4090] * 3 + [4096], 16) == 4 * 4096          # all within the last block: uniform enough
+    assert hint([4096] * 255 + [4080], 16) == 0               # one sequence a block short
+    assert hint([int(x) for x in np.random.default_rng(1).integers(2048, 4097, size=64)], 16) == 0
+    assert hint([100] * 4, 16, q_lens=[5] * 4) == 0           # verify rows: not the pure-decode case
+    assert hint([4096] * 8, 16, given=-1) == 0                # "known not uniform" stops the derivation
+    assert hint([17, 900], 16, given=12345) == 12345          # the caller's own value wins
+    assert uniform_kv_hint(0, 0, 1, 0, 0, 16) == 0
+
+
+def test_graph_variants_of_a_padded_capture_do_not_derive_a_hint():
+    """ModelRunner captures over padded static buffers: the non-uniform variant says so (kv_total_len < 0) instead of
+    leaving the derivation to a block table whose length is the capture-time maximum."""
+    import dataclasses
+    from scalellm_amd.layers import InputParameters, uniform_kv_hint
+    z = torch.zeros(5, dtype=torch.int32)
+    p = InputParameters(q_cu_seq_lens=z, kv_cu_seq_lens=z, new_cache_slots=z[:4], block_tables=torch.zeros(4 * 8, dtype=torch.int32),
+                        cu_block_lens=z, q_max_seq_len=1, kv_max_seq_len=128)
+    assert uniform_kv_hint(p.kv_total_len, 4, 1, 128, p.block_tables.numel(), 16) == 4 * 128   # would misfire ...
+    q = dataclasses.replace(p, kv_total_len=-1)
+    assert uniform_kv_hint(q.kv_total_len, 4, 1, 128, q.block_tables.numel(), 16) == 0         # ... unless told
