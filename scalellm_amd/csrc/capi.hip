@@ -21,6 +21,7 @@ const char* const kTuneNames[TUNE_COUNT] = {
     "SLM_W4_KS_DBG",        "SLM_W4_KS_MT2",
     "SLM_W4_M128",          "SLM_W4_M128_WD",       "SLM_W4_M128_SPLITS",   "SLM_W4_M128_KW",   "SLM_W4_SPLIT_TARGET",
     "SLM_W4_M128_CT",       "SLM_ATTN_TILE_KV2",    "SLM_W4_XL_MODEL",      "SLM_W4_M128_ADMA",
+    "SLM_W4_XL_SK",
 };
 std::atomic<int32_t> g_tune[TUNE_COUNT];
 std::once_flag g_tune_once;

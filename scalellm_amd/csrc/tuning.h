@@ -47,6 +47,7 @@ enum TuneKey : int {
   TUNE_ATTN_TILE_KV2,     // SLM_ATTN_TILE_KV2     two wave groups share a query tile's KV range in the prefill tile kernel: 1 always, 0 never (default: small plain-prefill grids)
   TUNE_W4_XL_MODEL,       // SLM_W4_XL_MODEL       0 = the 256 x 256 kernel only where its tiles fill whole rounds (no round-count comparison with 256 x 128 tiles)
   TUNE_W4_M128_ADMA,      // SLM_W4_M128_ADMA      activations of the 256-column form by LDS-DMA (1) or through registers (0)
+  TUNE_W4_XL_SK,          // SLM_W4_XL_SK          stream-K form of the 256 x 256 kernel: 0 never, 2 wherever it applies (default 1: where the round model says it wins)
   TUNE_COUNT
 };
 

@@ -521,6 +521,7 @@ constexpr bool w4_post_fits(int mt, int ntw, int ng, int pc) {
 constexpr bool w4_pre_fits(int /*mt*/, int ntw, int ng, int pc) { return !(ntw == 2 && ng == 4 && pc >= 2); }
 
 struct GemmPlan {
+  int xl_sk, sk_per;      // stream-K form of the 256 x 256 kernel (w4_xl.hip): 128-deep chunks per workgroup
   int mt, ntw, ng, pc, post, small, gemv, split_k, chunks_per_split, n_mblocks, n_nblocks;
   int ks, ks_cw, ks_nw, ks_tpw, ks_mt;  // K-sliced small-M kernel (w4_ks.hip)
   int m128, m128_wd, m128_kw, m128_ct, m128_adma;  // 65 <= M <= 128 kernel (w4_m128.hip)
@@ -548,6 +549,7 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   //            ~512 workgroups (2 per CU), split-K <= 8
   const int n_chunks = (int)(a->K / W4_KC);
   int mt;
+  int xl_sk = 0;
   if (a->M <= 32) mt = 1;
   else if (a->M <= 64) mt = 2;
   else if (a->M <= 128) {
@@ -584,6 +586,23 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
     if (a_fits && mt == 8 && rounds8 >= 2 && rounds * 100 < rounds8 * 58 && tiles16 * 100 >= rounds * 256 * 65 &&
         tune_get(TUNE_W4_XL_MODEL, 1) != 0)
       mt = 16;
+    // Round 6: the STREAM-K form of the 256 x 256 kernel (w4_xl.hip): the tile x K work cut into 256 equal ranges
+    // -- no round of tiles is left part-filled.  Cost model in units of one 256 x 256 tile's time: the chosen
+    // kernel's rounds (a 256 x 128 tile: 0.58) against 1.4 x tiles16 / 256 (measured 1.28...1.41 over M = 1536...3072:
+    // a second pipeline fill per workgroup, the partial tiles' round trip, a fuller chip's lower clock;
+    // profiles/r06_gemm_streamk.jsonl).  At least half a tile per
+    // workgroup (a tile is then cut into at most three pieces); not with the SiLU pair epilogue (gate_up fills
+    // its rounds), not next to another stream (its workgroups wait for each other: SLM_W4_SHARES_CHIP).
+    const int sk_mode = tune_get(TUNE_W4_XL_SK, 1);
+    if (a_fits && sk_mode != 0 && tiles16 >= 128 && a->N % 256 == 0 && !(a->flags & (SLM_W4_SILU_MUL | SLM_W4_SHARES_CHIP)) &&
+        !tune_is_set(TUNE_W4_MT) && !tune_is_set(TUNE_W4_SPLITK)) {
+      const double cur = mt == 16 ? (double)rounds : mt == 8 ? 0.58 * (double)rounds8 : 1e30;
+      const double sk = 1.40 * (double)tiles16 / 256.0;
+      if (sk_mode >= 2 || sk < 0.97 * cur) {
+        mt = 16;
+        xl_sk = 1;
+      }
+    }
   }
   // M <= 4: dot2 GEMV (w4_gemv.hip); M <= 32: the lean weight-streaming kernel (w4_small.hip)
   // (measured: the GEMV wins on every layer shape at M = 1 and loses on some at M = 2..4, so the
@@ -600,6 +619,7 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
   // 8 = wave-specialised 256 x 128 kernel (w4_ws.hip), 16 = symmetric 256 x 256 kernel (w4_xl.hip)
   if (mt != 1 && mt != 2 && mt != 4 && mt != 8 && mt != 16) mt = 4;
   if (mt >= 8 && ((a->M - 1) * a->lda + a->K) * 2 >= ((int64_t)1 << 31)) mt = 4;
+  if (mt != 16 || pl->small || pl->gemv) xl_sk = 0;
   int ntw = tune_get(TUNE_W4_NTW, 1);
   if (ntw != 1 && ntw != 2) ntw = 1;
   if (mt >= 4) ntw = 1;
@@ -801,7 +821,22 @@ static int plan_gemm(const slm_w4_gemm_args* a, GemmPlan* pl) {
     pl->m128_adma = ct == 8 && tune_get(TUNE_W4_M128_ADMA, 1) != 0;
     pl->lds_bytes = W4_M128_LDS_BYTES;
   }
+  pl->xl_sk = 0;
+  pl->sk_per = 0;
+  if (xl_sk && !pl->ks && !pl->m128 && pl->mt == 16) {
+    // equal ranges of the work list, in whole 64-deep chunk QUADS (the kernel's ring granularity: 2 chunks of 128)
+    const int64_t work = (int64_t)pl->n_mblocks * pl->n_nblocks * n_chunks;
+    int64_t per = (work + W4_XL_SK_WGS - 1) / W4_XL_SK_WGS;
+    per = (per + 1) & ~(int64_t)1;
+    if (per >= 2 && (n_chunks & 1) == 0 && per < ((int64_t)1 << 30)) {
+      pl->xl_sk = 1;
+      pl->sk_per = (int)per;
+      pl->split_k = 1;
+      pl->chunks_per_split = n_chunks;
+    }
+  }
   pl->part_bytes = pl->split_k > 1 ? (size_t)pl->split_k * a->M * a->N * sizeof(float) : 0;
+  if (pl->xl_sk) pl->part_bytes = W4_XL_SK_WGS * W4_XL_SK_SLOT_BYTES + W4_XL_SK_SYNC_BYTES;
   pl->aperm_bytes = a->perm ? (((size_t)a->M * a->K * 2 + 255) & ~(size_t)255) : 0;
   return SLM_OK;
 }
@@ -1020,6 +1055,14 @@ static int gemm_impl(const slm_w4_gemm_args* a, const slm_w4_norm_prologue* np, 
   kp.ks_tpw = pl.ks ? pl.ks_tpw : 0;
   kp.ks_groups = (int)(a->K / a->group_size);
   kp.ks_dbg = tune_get(TUNE_W4_KS_DBG, 0);
+  kp.sk_per = pl.sk_per; kp.sk_sync = nullptr; kp.sk_part = nullptr;
+  if (pl.xl_sk) {
+    kp.sk_part = reinterpret_cast<float*>(a->workspace);
+    kp.sk_sync = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(a->workspace) + W4_XL_SK_WGS * W4_XL_SK_SLOT_BYTES);
+    // the ticket and the flags start at zero on every call (a memset node under capture)
+    if (hipMemsetAsync(kp.sk_sync, 0, W4_XL_SK_SYNC_BYTES, st) != hipSuccess) return hip_check_launch();
+    launch_gemm_xl_sk(kp, a->dtype, pl.ng, W4_XL_SK_WGS, st);
+  } else
   if (pl.ks)
     launch_gemm_ks(kp, a->dtype, pl.ng, pl.ks_cw, pl.ks_nw, pl.n_nblocks * pl.split_k, st, pl.ks_mt);
   else if (pl.gemv)

@@ -173,6 +173,12 @@ struct GemmKParams {
   int ks_tpw;     // w4_ks.hip: consecutive column tiles per workgroup (n_nblocks = tile runs)
   int ks_groups;  // w4_ks.hip: K / group_size (rows of the scale table)
   int ks_dbg;     // w4_ks.hip: probe bits (SLM_W4_KS_DBG), 0 in production
+  // w4_xl.hip, stream-K form (round 6): workgroup g (a ticket drawn at start) owns the 128-deep chunks
+  // [g * sk_per, (g + 1) * sk_per) of the tile-major work list (tiles x n_chunks); sk_sync = {ticket, flag[g] ...},
+  // zero at launch; sk_part = one 256 x 256 fp32 tile image per workgroup (fragment-major)
+  int sk_per;
+  unsigned* sk_sync;
+  float* sk_part;
   // GEMV norm prologue (slm_w4a16_gemv_norm): activations = rms_norm(x + residual_in) * weight,
   // computed in the kernel; norm_weight == NULL: none, `a` is read as usual
   const void* norm_x;          // [M, K] T or NULL
@@ -279,6 +285,10 @@ constexpr size_t W4_WS_LDS_BYTES = 7 * (256 * 64) + 4 * (8 * 1024) + 2 * 4 * (10
 
 // symmetric 256 x 256 kernel for large M x N (w4_xl.hip): 512 threads, 160 KiB LDS
 void launch_gemm_xl(const GemmKParams& kp, int dtype, int ng, int n_blocks, hipStream_t st);
+void launch_gemm_xl_sk(const GemmKParams& kp, int dtype, int ng, int n_wgs, hipStream_t st);
+constexpr int W4_XL_SK_WGS = 256;                                  // one workgroup per CU (160 KiB of LDS each)
+constexpr size_t W4_XL_SK_SLOT_BYTES = 256 * 256 * sizeof(float);  // a partial tile
+constexpr size_t W4_XL_SK_SYNC_BYTES = 2048;                       // ticket + one flag per workgroup
 constexpr size_t W4_XL_LDS_BYTES = 7 * (256 * 64) + 3 * (16 * 1024);
 
 }  // namespace slm

@@ -35,27 +35,27 @@ static_assert(XL_AL <= XL_A_UNITS - 2, "slot of unit g + XL_AL was released befo
 // WNT: non-temporal weight loads -- right when every weight is read ONCE per launch (one block of 256
 // rows: the decode batch), wrong when several row blocks re-read the weights (prefill: cacheable lines
 // are served from L2 / Infinity Cache the second time; round 4: M = 1024 layer 533 -> 508 us)
-template <typename T, int NGC, bool WNT>
-__global__ void __launch_bounds__(512, 2) w4a16_gemm_xl_kernel(const GemmKParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// One output tile (column block nb, row block mb) over the 64-deep chunks [c0, c1) of K: prologue + main loop, the
+// sums left in `acc` (C^T accumulators).  MULTI: the caller runs several passes in one launch (the stream-K form
+// below): the pass ends drained (no DMA / load in flight, every wave past its last LDS read).
+template <typename T, int NGC, bool WNT, bool MULTI>
+__device__ __forceinline__ void xl_pass(const GemmKParams& p, char* smem, const int nb, const int mb, const int c0,
+                                        const int c1, f32x16 (&acc)[2][4]) {
   typedef typename Mfma<T>::frag frag_t;
 
-  const int tid = threadIdx.x;
+  int tid_ = threadIdx.x;
+  // (several passes per launch: keep hipcc from hoisting the per-lane address arithmetic out of the pass loop,
+  // where it would stay live -- or spill -- across the whole body)
+  if constexpr (MULTI) asm volatile("" : "+v"(tid_));
+  const int tid = tid_;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int bid = blockIdx.x;
-  const int nb = bid % p.n_nblocks;
-  bid /= p.n_nblocks;
-  const int mb = bid % p.n_mblocks;
-  const int ks = bid / p.n_mblocks;
   const int64_t m0 = (int64_t)mb * 256;
   const int64_t n_tiles = p.N / 32;
   const int mh = wave >> 2, nq = wave & 3;
   const int mrow = lane & 31, kh = lane >> 5;
+  (void)nq;
 
-  // chunk range of this split in 64-deep chunks (the plan counts 128-deep units); a step is half a chunk
-  const int c0 = 2 * ks * p.chunks_per_split;
-  const int c1 = 2 * min(p.n_chunks, (ks + 1) * p.chunks_per_split);
   const int n = c1 - c0;                                           // chunks, >= 2
   const int n_steps = 2 * ((n + XL_RING - 1) / XL_RING * XL_RING);  // main-loop steps
   const int last = c1 - 1;
@@ -124,7 +124,6 @@ __global__ void __launch_bounds__(512, 2) w4a16_gemm_xl_kernel(const GemmKParams
     __builtin_amdgcn_sched_barrier(0);
   }
 
-  f32x16 acc[2][4];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -221,9 +220,20 @@ __global__ void __launch_bounds__(512, 2) w4a16_gemm_xl_kernel(const GemmKParams
       dslot = dslot == XL_A_UNITS - 1 ? 0 : dslot + 1;
     }
   }
+  if constexpr (MULTI) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
-  // ---- epilogue (C^T accumulators: lane = token, 4 consecutive columns per r >> 2) ----
-  if (p.silu && p.split_k == 1) {
+// ---- epilogue (C^T accumulators: lane = token, 4 consecutive columns per r >> 2) ----
+// final = true: T(acc + bias) into c;  false: fp32 into the split-K slab `ks` of p.part
+template <typename T>
+__device__ __forceinline__ void xl_store(const GemmKParams& p, const f32x16 (&acc)[2][4], const int nb, const int mb,
+                                         const int ks, const bool final) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int64_t m0 = (int64_t)mb * 256;
+  const int64_t n_tiles = p.N / 32;
+  const int mh = wave >> 2, nq = wave & 3;
+  if (p.silu && final) {
     store_ct_silu_pair<T>(p, acc, (int64_t)nb * 8 + nq * 2, m0 + mh * 128 + (lane & 31), lane);
     return;
   }
@@ -236,7 +246,7 @@ __global__ void __launch_bounds__(512, 2) w4a16_gemm_xl_kernel(const GemmKParams
     for (int q = 0; q < 4; ++q) {
       const int64_t ncol = t * 32 + 8 * q + 4 * (lane >> 5);
       float bv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.split_k == 1 && p.bias) {
+      if (final && p.bias) {
         const u32x2 b = *reinterpret_cast<const u32x2*>(reinterpret_cast<const uint16_t*>(p.bias) + ncol);
         bv[0] = lo_f32<T>(b.x); bv[1] = hi_f32<T>(b.x);
         bv[2] = lo_f32<T>(b.y); bv[3] = hi_f32<T>(b.y);
@@ -247,7 +257,7 @@ __global__ void __launch_bounds__(512, 2) w4a16_gemm_xl_kernel(const GemmKParams
         if (row >= p.M) continue;
         const float v0 = acc[j][i][4 * q + 0], v1 = acc[j][i][4 * q + 1];
         const float v2 = acc[j][i][4 * q + 2], v3 = acc[j][i][4 * q + 3];
-        if (p.split_k == 1) {
+        if (final) {
           uint16_t* dst = reinterpret_cast<uint16_t*>(p.c) + row * p.ldc + ncol;
           u32x2 o;
           o.x = pack2<T>(v0 + bv[0], v1 + bv[1]);
@@ -264,6 +274,154 @@ __global__ void __launch_bounds__(512, 2) w4a16_gemm_xl_kernel(const GemmKParams
         }
       }
     }
+  }
+}
+
+template <typename T, int NGC, bool WNT>
+__global__ void __launch_bounds__(512, 2) w4a16_gemm_xl_kernel(const GemmKParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int bid = blockIdx.x;
+  const int nb = bid % p.n_nblocks;
+  bid /= p.n_nblocks;
+  const int mb = bid % p.n_mblocks;
+  const int ks = bid / p.n_mblocks;
+  // chunk range of this split in 64-deep chunks (the plan counts 128-deep units); a step is half a chunk
+  const int c0 = 2 * ks * p.chunks_per_split;
+  const int c1 = 2 * min(p.n_chunks, (ks + 1) * p.chunks_per_split);
+  f32x16 acc[2][4];
+  xl_pass<T, NGC, WNT, false>(p, smem, nb, mb, c0, c1, acc);
+  xl_store<T>(p, acc, nb, mb, ks, p.split_k == 1);
+}
+
+// ---- stream-K form (round 6) ---------------------------------------------------------------------------------
+// Tiles that do not fill whole rounds of the 256 CUs (M = 2648, N = 4096: 176 tiles = one 69 %-full round) leave
+// the rest of the chip idle for a whole tile time.  Here the WORK -- tiles x 128-deep chunks of K, tile-major --
+// is cut into 256 equal ranges, one per workgroup (the reference's own answer: Marlin's striped partition,
+// gemm_kernel.cuh:66-150).  A range is split at tile boundaries into pieces; the piece that reaches its tile's
+// last chunk OWNS the tile, an earlier piece is a PARTIAL: its fp32 sums go to the workgroup's slot (write-through
+// stores, fragment-major) and a flag.  A workgroup runs its partial piece FIRST (at most one: the head of its last
+// tile), then its owner pieces; the owner adds the partial slots of the workgroups in front of it -- which
+// wrote them first thing -- in workgroup order and stores the 16-bit tile: a fixed summation order, the same bits
+// launch after launch.  Workgroup indices are TICKETS drawn at start, so "the workgroups in front" are running or
+// done whatever the dispatch order; the waits are bounded (~2 s) all the same.  Hand-off as the guide's R1 recipe:
+// sc1 payload stores, every wave drains, barrier, one relaxed agent-scope flag store; the owner polls relaxed and
+// reads the slots past its L2 (sc1 loads).
+// Measured (profiles/r06_gemm_streamk.jsonl, M = 2648): qkv 186 -> 155 us, o 110 -> 105, down 351 -> 300; a range costs
+// ~1.4x its share of a tile's time (a second pipeline fill per workgroup, the partial tile's round trip -- ~9 us of
+// o's 105 --, and 256 busy CUs clock lower than 176), which is what the plan's model charges.  Giving each XCD
+// a run of consecutive tiles (tickets 8 j + x as group x, ranges inside the group) changed nothing (104.8 / 155.6 /
+// 300.2 us): the activations' L2 reuse is not what the ranges lose.
+__device__ __forceinline__ uint32_t xl_sk_frag_off(int slot, int wave, int f, int lane) {
+  return (uint32_t)slot * (uint32_t)W4_XL_SK_SLOT_BYTES + (uint32_t)(((wave * 32 + f) * 64 + lane) << 4);
+}
+
+template <typename T, int NGC, bool WNT>
+__global__ void __launch_bounds__(512, 2) w4a16_gemm_xl_sk_kernel(const GemmKParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // (the ticket is broadcast through the first word of the tile's own LDS -- all 160 KiB belong to the passes --
+  // before any pass touches it)
+  int* bc = reinterpret_cast<int*>(smem);
+  if (threadIdx.x == 0)
+    bc[0] = (int)__hip_atomic_fetch_add(p.sk_sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int g = __builtin_amdgcn_readfirstlane(bc[0]);
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int nc = p.n_chunks;
+  const int per = p.sk_per;
+  const int64_t W = (int64_t)p.n_mblocks * p.n_nblocks * nc;     // the work list, tile-major, in 128-deep chunks
+  const int64_t w0 = (int64_t)g * per;
+  if (w0 >= W) return;
+  const int64_t w1 = w0 + per < W ? w0 + per : W;
+  const int t_first = (int)(w0 / nc), t_last = (int)((w1 - 1) / nc);
+  const bool has_partial = w1 < (int64_t)(t_last + 1) * nc;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(p.sk_part, 0, (int)(W4_XL_SK_WGS * W4_XL_SK_SLOT_BYTES), 0x00020000);
+  unsigned* flags = p.sk_sync + 1;
+  f32x16 acc[2][4];
+  if (has_partial) {
+    const int64_t tb = (int64_t)t_last * nc;
+    const int k0 = (int)((w0 > tb ? w0 : tb) - tb), k1 = (int)(w1 - tb);
+    xl_pass<T, NGC, WNT, true>(p, smem, t_last % p.n_nblocks, t_last / p.n_nblocks, 2 * k0, 2 * k1, acc);
+    if (!(p.ks_dbg & 1))
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[j][i][4 * q], acc[j][i][4 * q + 1], acc[j][i][4 * q + 2], acc[j][i][4 * q + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
+                                                 (int)xl_sk_frag_off(g, wave, (j * 4 + i) * 4 + q, lane), 0, /*sc1*/ 16);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains ...
+    __syncthreads();                                    // ... then ONE lane publishes
+    if (threadIdx.x == 0) __hip_atomic_store(flags + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // owner pieces: whole tiles first, the tile that STARTS in the workgroups in front (k0 > 0: the tail of the
+  // first tile) LAST -- its partials were the first thing those workgroups did, and this workgroup has done all
+  // its other work by the time it asks for them (asked first, a two-chunk tail would wait for a 30-chunk head)
+  const int t_own_last = has_partial ? t_last - 1 : t_last;
+  const bool first_dep = w0 > (int64_t)t_first * nc;
+  const int n_own = t_own_last - t_first + 1;
+  for (int it = 0; it < n_own; ++it) {
+    const int t = first_dep ? (it + 1 < n_own ? t_first + 1 + it : t_first) : t_first + it;
+    const int64_t tb = (int64_t)t * nc;
+    const int k0 = (int)((w0 > tb ? w0 : tb) - tb);
+    xl_pass<T, NGC, WNT, true>(p, smem, t % p.n_nblocks, t / p.n_nblocks, 2 * k0, 2 * nc, acc);
+    if (k0 > 0 && !(p.ks_dbg & 2)) {   // the partial slots of the workgroups in front, in workgroup order
+      const int g_first = (int)(tb / per);
+      for (int gp = g_first; gp < g; ++gp) {
+        if (threadIdx.x == 0) {
+          const uint64_t t0 = wall_clock64();
+          while (__hip_atomic_load(flags + gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 200000000ull) break;   // ~2 s of the 100 MHz clock: never a hang
+          }
+        }
+        __syncthreads();
+        // (16 loads = 8 KiB per wave in flight per trip: the reads go past the L2, ~2 us each way)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          u32x4 pv[16];
+#pragma unroll
+          for (int f = 0; f < 16; ++f)
+            pv[f] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)xl_sk_frag_off(gp, wave, h * 16 + f, lane), 0, /*sc1*/ 16);
+#pragma unroll
+          for (int f = 0; f < 16; ++f) {
+            const f32x4 v = __builtin_bit_cast(f32x4, pv[f]);
+            const int i = f >> 2, q = f & 3;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[h][i][4 * q + e] += v[e];
+          }
+        }
+      }
+    }
+    xl_store<T>(p, acc, t % p.n_nblocks, t / p.n_nblocks, 0, true);
+  }
+}
+
+template <typename T, int NGC, bool WNT>
+static void launch_xl_sk(const GemmKParams& kp, int n_wgs, hipStream_t st) {
+  auto kfn = w4a16_gemm_xl_sk_kernel<T, NGC, WNT>;
+  static bool opted = false;  // > 64 KiB of dynamic LDS has to be opted into once per kernel
+  if (!opted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4_XL_LDS_BYTES);
+    opted = true;
+  }
+  hipLaunchKernelGGL(kfn, dim3((unsigned)n_wgs), dim3(512), W4_XL_LDS_BYTES, st, kp);
+}
+
+void launch_gemm_xl_sk(const GemmKParams& kp, int dtype, int ng, int n_wgs, hipStream_t st) {
+  // (several row blocks always re-read the weights here: cacheable loads)
+  if (dtype == SLM_BF16) {
+    if (ng == 4) launch_xl_sk<bf16_tag, 2, false>(kp, n_wgs, st);
+    else launch_xl_sk<bf16_tag, 1, false>(kp, n_wgs, st);
+  } else {
+    if (ng == 4) launch_xl_sk<f16_tag, 2, false>(kp, n_wgs, st);
+    else launch_xl_sk<f16_tag, 1, false>(kp, n_wgs, st);
   }
 }
 

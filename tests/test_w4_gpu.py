@@ -613,3 +613,99 @@ def test_shares_chip_flag_only_changes_the_plan(M, K, N):
         assert not torch.equal(outs[False], outs[True])
     else:
         assert torch.equal(outs[False], outs[True])
+
+
+# ---- round 6: the stream-K form of the 256 x 256 kernel (w4_xl.hip) ------------------------------------------
+def _sk_case(M, K, N, dtype, gs=128, fmt="awq", bias=False):
+    tdt = _tdtype(dtype)
+    case = helpers.make_quant_case(M + K + N, K, N, gs, fmt, dtype)
+    packed = _pack(case, dtype)
+    g = torch.Generator(device=DEV).manual_seed(K + M)
+    a = torch.randn(M, K, device=DEV, dtype=tdt, generator=g)
+    b = torch.randn(N, device=DEV, dtype=tdt, generator=g) if bias else None
+    return case, packed, a, b
+
+
+def _sk_run(a, packed, b, M, N, sk):
+    from scalellm_amd import kernels
+    with kernels.tuning(SLM_W4_XL_SK=sk):
+        c = torch.full((M, N), float("nan"), device=DEV, dtype=a.dtype)
+        kernels.gptq_gemm(a, packed, c, b)
+    return c
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+@pytest.mark.parametrize("M,K,N", [(2648, 4096, 4096), (2648, 4096, 6144), (2500, 14336, 4096), (2048, 4096, 4096),
+                                   (4000, 2048, 3072), (2304, 1024, 4096)])
+def test_stream_k_form_matches_the_oracle_and_the_tile_form(M, K, N, dtype):
+    """The tile x K work cut into 256 equal ranges (pieces of up to three workgroups meet in the owner's
+    epilogue): right against the oracle at the reference's GEMM tolerance, equal to the one-tile-per-workgroup form
+    up to the order of the fp32 partial sums, every output written (no NaN left), ragged M (rows past the last
+    full tile) included."""
+    case, packed, a, b = _sk_case(M, K, N, dtype, bias=(M % 8 == 0))
+    tile = _sk_run(a, packed, b, M, N, 0)
+    sk = _sk_run(a, packed, b, M, N, 2)
+    torch.cuda.synchronize()
+    assert not torch.isnan(sk.float()).any()
+    ref = oracle.gemm_f32(a.float().cpu().numpy(), _oracle_w(case))
+    if b is not None:
+        ref = ref + b.float().cpu().numpy()[None, :]
+    assert _rel_err(sk.float().cpu().numpy(), ref) < GEMM_TOL[dtype]
+    assert _rel_err(tile.float().cpu().numpy(), ref) < GEMM_TOL[dtype]
+    assert _rel_err(sk.float().cpu().numpy(), tile.float().cpu().numpy()) < 2e-3
+
+
+def test_stream_k_form_repeats_bit_identically_and_replays_under_a_graph():
+    """The owner adds the partial tiles of the workgroups in front of it in workgroup order, whoever finishes
+    first: 20 launches next to a bandwidth hog give the same bits; captured (the memset node that clears the ticket
+    and the flags + the kernel) and replayed, too."""
+    from scalellm_amd import kernels
+    M, K, N = 2648, 4096, 4096
+    case, packed, a, b = _sk_case(M, K, N, "bf16")
+    first = _sk_run(a, packed, b, M, N, 2)
+    hog_src = torch.randn(64 << 20, device=DEV, dtype=torch.bfloat16)
+    hog_dst = torch.empty_like(hog_src)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for i in range(8):
+            n = (i % 4 + 1) * (8 << 20)
+            hog_dst[:n].copy_(hog_src[:n])
+    outs = [_sk_run(a, packed, b, M, N, 2) for _ in range(20)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, first) for o in outs)
+    with kernels.tuning(SLM_W4_XL_SK=2):
+        c = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        kernels.gptq_gemm(a, packed, c)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            kernels.gptq_gemm(a, packed, c)
+            kernels.gptq_gemm(a, packed, c)   # (twice: the second call's memset node follows the first's kernel)
+        for _ in range(3):
+            c.fill_(float("nan"))
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(c, first)
+
+
+def test_stream_k_form_is_planned_where_the_round_model_says_so():
+    """Llama-3-8B layer shapes at the mixed step's 2648 rows: qkv / o / down leave a round of tiles part-filled and
+    take the stream-K form (no split-K slabs: a deferred call writes c itself); gate_up fills its rounds and does
+    not; a call that shares the chip never does."""
+    from scalellm_amd import _lib, kernels
+    import ctypes as C
+    L = _lib.lib()
+
+    def splits_and_ws(M, K, N, flags=0):
+        g = _lib.W4GemmArgs()
+        g.M, g.K, g.N, g.lda, g.ldc, g.group_size, g.dtype = M, K, N, K, N, 128, _lib.SLM_BF16
+        g.flags = flags
+        return int(L.slm_w4a16_gemm_workspace_bytes(C.byref(g)))
+    sk_ws = 256 * 256 * 256 * 4 + 2048
+    assert splits_and_ws(2648, 4096, 4096) == sk_ws
+    assert splits_and_ws(2648, 4096, 6144) == sk_ws
+    assert splits_and_ws(2648, 14336, 4096) == sk_ws
+    assert splits_and_ws(2648, 4096, 28672) != sk_ws
+    assert splits_and_ws(2648, 4096, 4096, _lib.SLM_W4_SHARES_CHIP) != sk_ws
+    with kernels.tuning(SLM_W4_XL_SK=0):
+        assert splits_and_ws(2648, 4096, 4096) != sk_ws
