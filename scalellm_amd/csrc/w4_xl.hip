@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(512, 2) w4a16_gemm_xl_kernel(const GemmKParams
 // tile), then its owner pieces; the owner adds the partial slots of the workgroups in front of it -- which
 // wrote them first thing -- in workgroup order and stores the 16-bit tile: a fixed summation order, the same bits
 // launch after launch.  Workgroup indices are TICKETS drawn at start, so "the workgroups in front" are running or
-// done whatever the dispatch order; the waits are bounded (~2 s) all the same.  Hand-off as the guide's R1 recipe:
+// done whatever the dispatch order; the waits are bounded all the same (~2 s, then a trap).  Hand-off as the guide's R1 recipe:
 // sc1 payload stores, every wave drains, barrier, one relaxed agent-scope flag store; the owner polls relaxed and
 // reads the slots past its L2 (sc1 loads).
 // Measured (profiles/r06_gemm_streamk.jsonl, M = 2648): qkv 186 -> 155 us, o 110 -> 105, down 351 -> 300; a range costs
@@ -377,7 +377,9 @@ __global__ void __launch_bounds__(512, 2) w4a16_gemm_xl_sk_kernel(const GemmKPar
           const uint64_t t0 = wall_clock64();
           while (__hip_atomic_load(flags + gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
             __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > 200000000ull) break;   // ~2 s of the 100 MHz clock: never a hang
+            // ~2 s of the 100 MHz clock: a partial that never comes is a broken launch -- fail loudly (the
+            // process aborts on the trap) rather than hang the GPU or store a tile that misses a piece
+            if (wall_clock64() - t0 > 200000000ull) __builtin_trap();
           }
         }
         __syncthreads();
