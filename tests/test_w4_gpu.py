@@ -709,3 +709,18 @@ def test_stream_k_form_is_planned_where_the_round_model_says_so():
     assert splits_and_ws(2648, 4096, 4096, _lib.SLM_W4_SHARES_CHIP) != sk_ws
     with kernels.tuning(SLM_W4_XL_SK=0):
         assert splits_and_ws(2648, 4096, 4096) != sk_ws
+
+
+@pytest.mark.parametrize("gs,fmt", [(32, "gptq"), (64, "awq"), (-1, "gptq")])
+def test_stream_k_form_other_group_sizes(gs, fmt):
+    """group 32 (two scale groups per 64-deep chunk: its own instantiation), 64 and per-channel scales"""
+    M, K, N = 2304, 2048, 4096
+    case, packed, a, b = _sk_case(M, K, N, "bf16", gs=gs if gs > 0 else K, fmt=fmt)
+    tile = _sk_run(a, packed, b, M, N, 0)
+    sk = _sk_run(a, packed, b, M, N, 2)
+    again = _sk_run(a, packed, b, M, N, 2)
+    torch.cuda.synchronize()
+    ref = oracle.gemm_f32(a.float().cpu().numpy(), _oracle_w(case))
+    assert _rel_err(sk.float().cpu().numpy(), ref) < GEMM_TOL["bf16"]
+    assert _rel_err(sk.float().cpu().numpy(), tile.float().cpu().numpy()) < 2e-3
+    assert torch.equal(sk, again)
