@@ -29,8 +29,8 @@ Stated tolerance (relative L2 error of the logits, per step), Llama bf16 stacks,
     the twin is only 2-3x tighter than the fp32 reference and not 100x.
 GPT-2 (12 layers, the whole residual stream in the 16-bit dtype) <= 3e-2 bf16 / 4e-3 fp16; greedy
 token ids identical wherever the reference's top-2 margin exceeds 4x the largest absolute logit
-error of that row (a smaller margin is a coin flip at any 16-bit precision), and in >= 90 % of
-all rows overall.
+error of that row (a smaller margin is a coin flip at any 16-bit precision), and in >= 97 % of
+all rows overall (two rows of a 20-row set; observed in round 6: 19/20 ... 319/320, printed by every test).
 """
 import numpy as np
 import pytest
@@ -137,7 +137,9 @@ def test_llama_prefill_then_decode_logits_match_oracle(name):
         seqs.feed(inp, got.argmax(-1))
     print(f"[e2e] {name}: per-step relative L2 error (vs fp32 oracle, vs bf16-storage twin): {rels}; "
           f"greedy ids equal on {agree}/{total} rows")
-    assert agree >= 0.9 * total, f"{name}: greedy ids agree on only {agree}/{total} rows"
+    # observed (round 6, one MI355X): 19/20, 20/20, 20/20, 162/165, 20/20, 19/20 -- every miss a near tie (a decisive
+    # top-2 margin with a different id already failed in check_logits).  The bar: 97 %, or two near ties of a small set
+    assert agree >= min(0.97 * total, total - 2), f"{name}: greedy ids agree on only {agree}/{total} rows"
 
 
 @pytest.mark.parametrize("host", ["py", "cpp"])
@@ -183,7 +185,8 @@ def test_llama_two_lane_decode_step_and_cpp_host_match_oracle(host):
         check_logits(got, twin_model.forward(inp), 1.5e-2, f"two lanes ({host}) step {si} vs bf16-storage twin")
         seqs.advance(new_lens)
         seqs.feed(inp, got.argmax(-1))
-    assert agree >= 0.9 * total, f"greedy ids agree on only {agree}/{total} rows"
+    print(f"[e2e] greedy ids equal on {agree}/{total} rows")
+    assert agree >= min(0.97 * total, total - 2), f"greedy ids agree on only {agree}/{total} rows"
 
 
 def _all_row_check(h_got, lm_head_f32, ref_model, twin_model, inp, what):
@@ -470,4 +473,5 @@ def test_gpt2_small_config1_logits_match_hf_fp32(dtype):
         agree, total = agree + a, total + n
         seqs.feed(inp, got.argmax(-1))
         new_lens = [1] * len(prompt_lens)
-    assert agree >= 0.9 * total, f"greedy ids agree on only {agree}/{total} rows"
+    print(f"[e2e] gpt2 {dtype}: greedy ids equal on {agree}/{total} rows")
+    assert agree >= min(0.97 * total, total - 2), f"greedy ids agree on only {agree}/{total} rows"
