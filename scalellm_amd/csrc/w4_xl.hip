@@ -407,11 +407,13 @@ __global__ void __launch_bounds__(512, 2) w4a16_gemm_xl_sk_kernel(const GemmKPar
 template <typename T, int NGC, bool WNT>
 static void launch_xl_sk(const GemmKParams& kp, int n_wgs, hipStream_t st) {
   auto kfn = w4a16_gemm_xl_sk_kernel<T, NGC, WNT>;
-  static bool opted = false;  // > 64 KiB of dynamic LDS has to be opted into once per kernel
-  if (!opted) {
+  static bool opted[64] = {};  // > 64 KiB of dynamic LDS: opted into once per kernel AND per device
+  int devi = 0;
+  (void)hipGetDevice(&devi);
+  if (devi < 0 || devi >= 64 || !opted[devi]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4_XL_LDS_BYTES);
-    opted = true;
+    if (devi >= 0 && devi < 64) opted[devi] = true;
   }
   hipLaunchKernelGGL(kfn, dim3((unsigned)n_wgs), dim3(512), W4_XL_LDS_BYTES, st, kp);
 }
@@ -430,11 +432,13 @@ void launch_gemm_xl_sk(const GemmKParams& kp, int dtype, int ng, int n_wgs, hipS
 template <typename T, int NGC, bool WNT>
 static void launch_xl(const GemmKParams& kp, int n_blocks, hipStream_t st) {
   auto kfn = w4a16_gemm_xl_kernel<T, NGC, WNT>;
-  static bool opted = false;  // > 64 KiB of dynamic LDS has to be opted into once per kernel
-  if (!opted) {
+  static bool opted[64] = {};  // > 64 KiB of dynamic LDS: opted into once per kernel AND per device
+  int devi = 0;
+  (void)hipGetDevice(&devi);
+  if (devi < 0 || devi >= 64 || !opted[devi]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)W4_XL_LDS_BYTES);
-    opted = true;
+    if (devi >= 0 && devi < 64) opted[devi] = true;
   }
   hipLaunchKernelGGL(kfn, dim3((unsigned)n_blocks), dim3(512), W4_XL_LDS_BYTES, st, kp);
 }
