@@ -724,3 +724,26 @@ def test_stream_k_form_other_group_sizes(gs, fmt):
     assert _rel_err(sk.float().cpu().numpy(), ref) < GEMM_TOL["bf16"]
     assert _rel_err(sk.float().cpu().numpy(), tile.float().cpu().numpy()) < 2e-3
     assert torch.equal(sk, again)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_stream_k_form_seeded_fuzz(seed):
+    """Random shapes through the range / piece / owner arithmetic: ranges shorter and longer than a tile, a last range
+    that is cut short, row counts that leave the last row block part-empty -- against the tile form (same kernel body,
+    one tile per workgroup) and repeatable bit for bit."""
+    rng = np.random.default_rng(100 + seed)
+    for _ in range(4):
+        n_nb = int(rng.integers(8, 25))                    # 256-column blocks
+        n_mb = int(rng.integers(max(6, (128 + n_nb - 1) // n_nb), 18))   # row blocks: >= 128 tiles in all
+        M = 256 * (n_mb - 1) + int(rng.integers(1, 257))
+        K = 256 * int(rng.integers(2, 13))                 # an even number of 128-deep chunks
+        N = 256 * n_nb
+        case, packed, a, b = _sk_case(M, K, N, "bf16", bias=bool(rng.integers(0, 2)))
+        tile = _sk_run(a, packed, b, M, N, 0)
+        sk = _sk_run(a, packed, b, M, N, 2)
+        again = _sk_run(a, packed, b, M, N, 2)
+        torch.cuda.synchronize()
+        assert not torch.isnan(sk.float()).any(), (M, K, N)
+        assert torch.equal(sk, again), (M, K, N)
+        err = _rel_err(sk.float().cpu().numpy(), tile.float().cpu().numpy())
+        assert err < 2e-3, (M, K, N, err)
