@@ -18,6 +18,7 @@ stale); only the timing is read.
      only_<x>        attention + one component
      slab1           full, but the consumers read ONE slab (what an in-kernel reduce would leave them)
      nodefer         full with SLM_DEFER_SPLITK=0 semantics (stand-alone reduce kernels)
+     w2copies        full, but lane 1 reads its own copy of every layer's weights (no Infinity-Cache sharing with lane 0)
   plus any `NAME=VALUE,...` tuning string applied on top (e.g. "full:SLM_W4_SPLIT_TARGET=256").
 
   python tools/ablate_step.py --variants "full;attn_only;gemms_only;glue_only" --out gpurun_out/x.jsonl
@@ -40,6 +41,11 @@ class AblatedStep(LlamaDecodeStep):
     on = set(ALL)
     slab1 = False
     defer = True
+    layers_lane1 = None   # variant `w2copies`: lane 1 reads its OWN copy of every layer's weights (nothing to share
+                          # with lane 0 in the Infinity Cache): what the second reader's cache hits are worth today
+
+    def _lw(self, ln, li):
+        return self.layers_lane1[li] if (self.layers_lane1 is not None and ln.idx == 1) else self.layers[li]
 
     def _consume(self, ln, x, handle, res, weight):
         if handle and self.slab1:
@@ -52,7 +58,7 @@ class AblatedStep(LlamaDecodeStep):
             kernels.rms_norm(ln.normed, ln.resid, self.layers[0]["in_norm"], self.shape.rms_eps)
 
     def _pre_attn(self, ln, li):
-        L, D = self.layers[li], self.shape.head_dim
+        L, D = self._lw(ln, li), self.shape.head_dim
         handle = None
         if "qkv" in self.on:
             L["qkv"].forward(ln.normed, out=ln.qkv, defer_splitk=self.defer)
@@ -67,7 +73,7 @@ class AblatedStep(LlamaDecodeStep):
             ln.q = q.view(ln.T, self.n_heads, D)
 
     def _post_attn(self, ln, li):
-        L = self.layers[li]
+        L = self._lw(ln, li)
         attn = ln.attn.view(ln.T, -1)
         handle = None
         if "o" in self.on:
@@ -88,7 +94,7 @@ class AblatedStep(LlamaDecodeStep):
 
 
 def variant_set(name):
-    if name == "full" or name == "slab1" or name == "nodefer":
+    if name in ("full", "slab1", "nodefer", "w2copies"):
         return set(ALL)
     if name == "attn_only":
         return set()
@@ -139,6 +145,13 @@ def main():
             k, v = kv.split("=")
             _lib.check(_lib.lib().slm_tuning_set(k.encode(), int(v)), k)
         step.on = variant_set(name)
+        step.layers_lane1 = None
+        if name == "w2copies":
+            import copy
+            if getattr(step, "_layers_copy", None) is None:
+                step._layers_copy = [dict(L, **{k: copy.deepcopy(L[k]) for k in ("qkv", "o", "gate_up", "down")})
+                                     for L in step.layers]
+            step.layers_lane1 = step._layers_copy
         step.slab1 = name == "slab1"
         step.defer = name != "nodefer"
         try:
